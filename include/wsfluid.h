@@ -1,0 +1,206 @@
+/*
+ * wsfluid.h -- C ABI of the MI355X-native SPH fluid step (libwsfluid.so).
+ *
+ * This is the drop-in boundary for the one hot path of qts8n/water-sandbox: the
+ * per-frame SPH step that the reference builds in src/fluid_compute.rs and runs as
+ * assets/simulation.wgsl + assets/bitonic_sort.wgsl through bevy_app_compute's
+ * AppComputeWorker.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  The reference-side binding (the Rust
+ * `extern "C"` block and the Bevy systems that call it) is in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; the library owns all device memory;
+ * the caller owns every pointer it passes and the library never keeps one after the
+ * call returns; every function returns a ws_status (0 = ok) and never throws or
+ * aborts; a handle is not re-entrant (calls on one handle must be serialised by the
+ * caller -- Bevy's ResMut does this) but may be used from any host thread.
+ * There is NO CPU fallback: without a gfx950 device ws_create fails with
+ * WS_ERR_NO_DEVICE.
+ */
+#ifndef WSFLUID_H
+#define WSFLUID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS_ABI_VERSION 1
+
+typedef enum ws_status {
+    WS_OK = 0,
+    WS_ERR_INVALID_ARG = 1,   /* null pointer, n == 0, non-finite / non-positive h, empty box */
+    WS_ERR_NO_DEVICE = 2,     /* no HIP device / not gfx950 / bad device index */
+    WS_ERR_OUT_OF_MEMORY = 3, /* hipMalloc failed or the cell grid would not fit */
+    WS_ERR_HIP = 4,           /* any other HIP runtime error (text in ws_last_error) */
+    WS_ERR_COMM = 5,          /* RCCL error in the multi-GPU halo exchange */
+    WS_ERR_UNSUPPORTED = 6,   /* e.g. bit-exact reference views for non power-of-two N */
+    WS_ERR_NOT_READY = 7      /* ws_try_* variants only */
+} ws_status;
+
+/*
+ * Everything the reference uploads as uniforms, in one POD.
+ *   fields 0..6   FluidStaticProps        src/fluid_compute.rs:41-51 (defaults :20-27,:67-79)
+ *   gravity       Gravity.value           src/gravity.rs:9-13 (default (0,-9.8,0,0) :29-33)
+ *   ext_min/max   FluidContainerExt       src/fluid_container.rs:17-22, from get_ext(0.1) :42-50
+ * The five SmoothingKernel constants (src/fluid_compute.rs:30-38) are NOT passed in:
+ * the library derives them exactly as get_smoothing_kernel does (:55-63) whenever
+ * smoothing_radius is set, which is what update() does every frame (:480).
+ */
+typedef struct ws_params {
+    float delta_time;
+    float collision_damping;
+    float smoothing_radius;
+    float target_density;
+    float pressure_scalar;
+    float near_pressure_scalar;
+    float viscosity_strength;
+    float reserved0; /* must be 0 */
+    float gravity[4];
+    float ext_min[4];
+    float ext_max[4];
+} ws_params;
+
+/* SmoothingKernel, src/fluid_compute.rs:30-38 */
+typedef struct ws_smoothing_kernel {
+    float pow2;
+    float pow2_der;
+    float pow3;
+    float pow3_der;
+    float spikey_pow3;
+} ws_smoothing_kernel;
+
+/* FluidParticle, src/fluid_compute.rs:106-115 == assets/simulation.wgsl:69-76.
+ * 80 bytes, same field order and offsets, so a Rust Vec<FluidParticle> can be
+ * passed straight in and out. */
+typedef struct ws_particle80 {
+    float position[4];
+    float density[2];
+    float pressure[2];
+    float velocity[4];
+    float acceleration[4];
+    float predicted_position[4];
+} ws_particle80;
+
+/* Placement of this handle's share of the domain.  Zero-initialise for one GPU. */
+typedef struct ws_device_cfg {
+    int32_t device;       /* HIP device ordinal */
+    uint32_t flags;       /* WS_FLAG_* */
+    uint32_t rank;        /* slab index along x, 0-based (0 for one GPU) */
+    uint32_t world_size;  /* number of slabs (0 or 1 = single GPU) */
+    uint32_t capacity;    /* max particles this handle may own (0 = n); multi-GPU
+                             handles need head-room for migration */
+    uint32_t reserved[3];
+} ws_device_cfg;
+
+#define WS_FLAG_NONE 0u
+#define WS_FLAG_PROFILE 1u /* record HIP events around every kernel of ws_step */
+
+typedef struct ws_handle ws_handle;
+
+/* ---- host-side functions of the path (pure CPU, no device needed) ----------- */
+
+/* FluidStaticProps::default + Gravity::default + FluidContainer::default().get_ext(0.1)
+ * (src/fluid_compute.rs:67-79, src/gravity.rs:29-33, src/fluid_container.rs:8-9,34-40). */
+ws_status ws_default_params(ws_params *out);
+/* FluidStaticProps::get_smoothing_kernel, src/fluid_compute.rs:55-63. */
+ws_status ws_get_smoothing_kernel(const ws_params *p, ws_smoothing_kernel *out);
+/* helpers::cube_fluid, src/helpers.rs:3-20. out_xyz holds ni*nj*nk*3 floats. */
+ws_status ws_cube_fluid(uint32_t ni, uint32_t nj, uint32_t nk, float particle_rad, float *out_xyz);
+/* FluidContainer::get_ext, src/fluid_container.rs:42-50. */
+ws_status ws_get_ext(const float position[3], const float size[3], float padding,
+                     float ext_min[4], float ext_max[4]);
+/* FluidWorker::get_bit_sorter_stages count, src/fluid_compute.rs:251-273.  The HIP
+ * path does not run the network; exposed because the reference prints it (:321). */
+uint32_t ws_bit_sorter_stage_count(uint32_t data_length);
+const char *ws_status_string(ws_status s);
+uint32_t ws_abi_version(void);
+
+/* ---- lifetime: replaces FluidWorker::build + AppComputeWorkerBuilder --------- */
+
+/* src/fluid_compute.rs:277-366.  pos_xyz: n*3 floats, particle id = index (the id
+ * FluidParticleLabel carries, :416-417,:459).  Uploads the particles with
+ * position = predicted_position = point and everything else 0 (:118-130), identity
+ * permutation (:293).  cfg may be NULL (device 0, single GPU). */
+ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n,
+                    const ws_device_cfg *cfg, ws_handle **out);
+ws_status ws_destroy(ws_handle *h);
+
+/* ---- per frame ---------------------------------------------------------------- */
+
+/* AppComputeWorker::run in ShaderPhysicsSet::Pass (src/fluid_compute.rs:396): enqueue
+ * one full step hash -> sort -> cell starts -> density -> force -> integrate
+ * (pass order :309-363) on the handle's stream and return without waiting. */
+ws_status ws_step(ws_handle *h);
+/* AppComputeWorker::ready (src/fluid_compute.rs:474,:511): *ready = 1 when every
+ * enqueued step has finished, else 0.  Never blocks. */
+ws_status ws_ready(ws_handle *h, int *ready);
+/* Block until every enqueued step has finished (the reference has no equivalent; its
+ * host simply skips the frame while !ready()). */
+ws_status ws_sync(ws_handle *h);
+/* The three worker.write calls of update() (src/fluid_compute.rs:479-481):
+ * fluid_props, smoothing_kernel (re-derived here) and gravity; the container is
+ * taken too (the reference uploads it once, :302).  Takes effect at the next ws_step. */
+ws_status ws_set_params(ws_handle *h, const ws_params *params);
+/* worker.read_vec::<FluidParticle>("particles") followed by `.position.xyz()` per
+ * label (src/fluid_compute.rs:478,:483-485): n*3 floats in ORIGINAL-ID order.
+ * Waits for enqueued steps first. */
+ws_status ws_read_positions(ws_handle *h, float *out_xyz);
+/* The full read_vec view (src/fluid_compute.rs:478): n records of 80 bytes in
+ * original-id order.  density/pressure/acceleration are the values the last step
+ * computed (0 before the first step). */
+ws_status ws_read_particles(ws_handle *h, ws_particle80 *out);
+/* despawn_liquid's four write_slice calls (src/fluid_compute.rs:517-524): particles
+ * <- initial state from pos_xyz, index buffers <- identity. */
+ws_status ws_reset(ws_handle *h, const float *pos_xyz);
+/* worker.write_slice("particles", ..) with an arbitrary state (position, velocity,
+ * predicted_position are taken; the other fields are recomputed by the next step
+ * before they are read, as in the reference).  Checkpoint/restore and the tests'
+ * teacher forcing use this. */
+ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
+
+/* ---- reference-layout views of the sort (diagnostic; computed on demand by HIP
+ *      kernels, never inside ws_step) ---------------------------------------------
+ * What the reference's three index buffers hold after the same number of steps:
+ *   keys[id]    = particle_cell_indicies: hash_cell(get_cell(predicted)) % N of the
+ *                 predicted position the last step STARTED from
+ *                 (assets/simulation.wgsl:121-141)
+ *   perm[slot]  = particle_indicies: a permutation with keys[perm] ascending.  The
+ *                 reference's bitonic network is unstable, so only the key SEQUENCE
+ *                 keys[perm[.]] is comparable bit for bit; this library returns the
+ *                 stable order (ties by ascending particle id).
+ *   offsets[k]  = cell_offsets: first slot of key k or 999999999
+ *                 (assets/bitonic_sort.wgsl:48-59)
+ * Before the first step all three are the identity (src/fluid_compute.rs:306-308).
+ * Any of the three output pointers may be NULL. */
+ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm,
+                            uint32_t *cell_offsets);
+
+/* ---- introspection ------------------------------------------------------------- */
+const char *ws_last_error(ws_handle *h);
+uint32_t ws_num_particles(ws_handle *h);
+uint64_t ws_steps_done(ws_handle *h);
+
+/* Kernel ids for ws_profile_read (stable; names via ws_kernel_name). */
+enum {
+    WS_K_SCAN = 0,     /* cell-count exclusive scan (3 launches)                */
+    WS_K_SCATTER = 1,  /* slot assignment inside each cell                      */
+    WS_K_REORDER = 2,  /* stable in-cell order + physical SoA reorder           */
+    WS_K_DENSITY = 3,  /* K4 update_density                                     */
+    WS_K_FORCE = 4,    /* K5 update_pressure_force + K6 integrate + next K1 bin */
+    WS_K_BIN = 5,      /* stand-alone cell binning (first step after upload)    */
+    WS_K_COUNT = 6
+};
+const char *ws_kernel_name(uint32_t kernel_id);
+/* With WS_FLAG_PROFILE: total milliseconds and launch count per kernel id since the
+ * last ws_profile_reset, measured with HIP events on the handle's own stream.  Waits
+ * for enqueued steps. */
+ws_status ws_profile_read(ws_handle *h, uint32_t kernel_id, double *total_ms, uint64_t *launches);
+ws_status ws_profile_reset(ws_handle *h);
+/* Device cell grid actually in use (cells along x,y,z incl. padding). */
+ws_status ws_grid_dims(ws_handle *h, uint32_t dims[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

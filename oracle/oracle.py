@@ -86,6 +86,18 @@ def build(force=False):
 _lib = None
 
 
+def default_threads():
+    """OpenMP threads the oracle uses: $WSO_THREADS, else min(affinity, 16)."""
+    env = os.environ.get("WSO_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -119,6 +131,8 @@ def lib():
         L.wso_step.argtypes = [C.POINTER(_State), C.c_int]
         L.wso_max_threads.restype = C.c_int
         L.wso_set_threads.argtypes = [C.c_int]
+        # a GPU box shows every host core but grants a share of them: cap the OpenMP team
+        L.wso_set_threads(default_threads())
         _lib = L
     return _lib
 

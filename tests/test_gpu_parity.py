@@ -1,0 +1,78 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on identical
+inputs.  Integer artefacts bit-exact; floats within 4x the oracle's own reorder noise, always
+ONE step from identical state (teacher forcing), SURVEY.md 8(c)."""
+import numpy as np
+import pytest
+
+from util import assert_particles_close, oracle_from_params, oracle_one_step, reorder_noise_tolerances
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_sort_view(O, orc, worker):
+    keys, perm, off = worker.sort_view()
+    # per-particle hash keys: bit-exact
+    assert np.array_equal(keys, orc.particle_cell_indicies)
+    # permutation validity + sorted key sequence bit-exact
+    assert np.array_equal(np.sort(perm), np.arange(orc.n, dtype=np.uint32))
+    assert np.array_equal(keys[perm], orc.sorted_keys())
+    # cell offsets (first slot per key or INF): bit-exact
+    assert np.array_equal(off, orc.cell_offsets)
+
+
+def _teacher_forced(O, ws, pos, params, steps, label):
+    orc = oracle_from_params(O, pos, params)
+    worker = ws.FluidWorker(pos, params)
+    state = orc.particles.copy()
+    for s in range(steps):
+        want = oracle_one_step(O, orc, state)
+        if s < 3:
+            worker.write_slice("particles", state)
+            worker.run()
+            _check_sort_view(O, orc, worker)
+        else:
+            worker.write_slice("particles", state)
+            worker.run()
+        got = worker.read_vec("particles")
+        rev = oracle_one_step(O, orc, state, reverse=True)
+        tol = reorder_noise_tolerances(want, rev)
+        assert_particles_close(got, want, tol, "%s step %d" % (label, s))
+        assert np.array_equal(worker.read_positions(), got["position"][:, :3])
+        state = want
+    worker.close()
+
+
+def test_lattice_4096_cube(oracle, ws):
+    pos = ws.cube_fluid(16, 16, 16)
+    _teacher_forced(oracle, ws, pos, ws.default_params(), 6, "cube16")
+
+
+def test_planar_c1_lattice(oracle, ws):
+    pos, params = ws.workloads.make_workload("c1", "lattice")
+    _teacher_forced(oracle, ws, pos, params, 4, "c1-lattice")
+
+
+def test_planar_c1_cloud(oracle, ws):
+    pos, params = ws.workloads.make_workload("c1", "cloud")
+    _teacher_forced(oracle, ws, pos, params, 4, "c1-cloud")
+
+
+def test_reference_default_65536(oracle, ws):
+    pos, params = ws.workloads.make_workload("ref", "lattice")
+    _teacher_forced(oracle, ws, pos, params, 3, "ref-65536")
+
+
+def test_free_running_matches_first_steps(oracle, ws):
+    """Free-running (no teacher forcing) GPU vs oracle for a few steps: reported drift must stay
+    small early on; integer keys stay bit-exact as long as positions agree to the cell."""
+    pos = ws.cube_fluid(16, 16, 16)
+    params = ws.default_params()
+    orc = oracle_from_params(oracle, pos, params)
+    worker = ws.FluidWorker(pos, params)
+    for s in range(5):
+        orc.step(oracle.SORT_EXACT)
+        worker.run()
+    got = worker.read_vec("particles")
+    err = np.max(np.abs(got["position"] - orc.particles["position"]))
+    assert err < 1e-3
+    worker.close()

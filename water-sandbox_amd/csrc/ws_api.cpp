@@ -1,0 +1,708 @@
+// ws_api.cpp -- the C ABI of include/wsfluid.h: handle lifetime, device buffers, the
+// per-step launch sequence and the readback paths.  Host-only logic; all device work is
+// in ws_kernels.hip.  The role played here is the one bevy_app_compute's
+// AppComputeWorker plays in the reference (src/fluid_compute.rs:277-366,:393-397).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "ws_internal.h"
+
+namespace {
+
+constexpr int kGridPad = 2;                     // empty cell layers around the container
+constexpr uint64_t kMaxCells = 1ull << 29;      // 3 x u32 per cell -> 6 GiB of tables
+
+thread_local std::string g_create_error;
+
+ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (h)
+        h->err = buf;
+    else
+        g_create_error = buf;
+    return st;
+}
+
+#define HIP_TRY(h, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(h, e_ == hipErrorOutOfMemory ? WS_ERR_OUT_OF_MEMORY : WS_ERR_HIP, #expr, e_); \
+    } while (0)
+
+// Rust f32::powi -> llvm.powi -> compiler-rt __powisf2 (square-and-multiply).
+float powi_f32(float a, int b)
+{
+    float r = 1.0f;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return r;
+}
+
+// Largest float T with sqrtf(T) <= h, so that (d2 > T) == (sqrtf(d2) > h) for every d2.
+float accept_threshold(float h)
+{
+    float t = h * h;
+    while (sqrtf(t) > h) t = nextafterf(t, 0.0f);
+    for (;;) {
+        const float up = nextafterf(t, INFINITY);
+        if (sqrtf(up) <= h)
+            t = up;
+        else
+            break;
+    }
+    return t;
+}
+
+bool is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
+
+uint32_t ref_hash_delta(int x, int y, int z, uint32_t n)
+{
+    return ((uint32_t)x * 15823u + (uint32_t)y * 9737333u + (uint32_t)z * 440817757u) % n;
+}
+
+ws_status validate_params(ws_handle *h, const ws_params *p)
+{
+    if (!p) return fail(h, WS_ERR_INVALID_ARG, "params is NULL");
+    if (!(p->smoothing_radius > 0.0f) || !isfinite(p->smoothing_radius))
+        return fail(h, WS_ERR_INVALID_ARG, "smoothing_radius must be finite and > 0");
+    for (int c = 0; c < 3; c++) {
+        if (!isfinite(p->ext_min[c]) || !isfinite(p->ext_max[c]) || p->ext_min[c] > p->ext_max[c])
+            return fail(h, WS_ERR_INVALID_ARG, "container ext_min/ext_max must be finite with ext_min <= ext_max");
+    }
+    return WS_OK;
+}
+
+// Fill the by-value kernel parameter block from the ABI params.
+ws_status derive_dev(ws_handle *h, const ws_params &p, uint32_t n, WsDev *out)
+{
+    WsDev d{};
+    d.dt = p.delta_time;
+    d.damping = p.collision_damping;
+    d.h = p.smoothing_radius;
+    d.target_density = p.target_density;
+    d.pressure_scalar = p.pressure_scalar;
+    d.near_pressure_scalar = p.near_pressure_scalar;
+    d.viscosity = p.viscosity_strength;
+    ws_smoothing_kernel sk;
+    ws_get_smoothing_kernel(&p, &sk);
+    d.k_pow2 = sk.pow2;
+    d.k_pow2_der = sk.pow2_der;
+    d.k_pow3 = sk.pow3;
+    d.k_pow3_der = sk.pow3_der;
+    d.k_spikey = sk.spikey_pow3;
+    for (int c = 0; c < 3; c++) {
+        d.grav[c] = p.gravity[c];
+        d.ext_min[c] = p.ext_min[c];
+        d.ext_max[c] = p.ext_max[c];
+    }
+    d.d2_accept = accept_threshold(d.h);
+    uint64_t cells = 1;
+    for (int c = 0; c < 3; c++) {
+        const double lo = floor((double)floorf(p.ext_min[c] / d.h)) - kGridPad;
+        const double hi = floor((double)floorf(p.ext_max[c] / d.h)) + kGridPad;
+        const double dim = hi - lo + 1.0;
+        if (!(fabs(lo) < 1e9) || !(dim < 1e9)) return fail(h, WS_ERR_INVALID_ARG, "container / smoothing_radius out of range");
+        d.org[c] = (int32_t)lo;
+        d.dim[c] = (int32_t)dim;
+        cells *= (uint64_t)d.dim[c];
+        if (cells > kMaxCells)
+            return fail(h, WS_ERR_OUT_OF_MEMORY, "cell grid too large (container volume / smoothing_radius^3 > 2^29)");
+    }
+    d.ncells = (uint32_t)cells;
+    d.guard = d.dim[1] * d.dim[2] + d.dim[2] + 1;
+    d.n = n;
+    d.hash_n = n;
+    h->sk = sk;
+    *out = d;
+    return WS_OK;
+}
+
+void free_grid(ws_handle *h)
+{
+    hipFree(h->count);
+    hipFree(h->cursor);
+    hipFree(h->start);
+    hipFree(h->bsum);
+    h->count = h->cursor = h->start = h->bsum = nullptr;
+    h->grid_alloc_cells = 0;
+}
+
+ws_status alloc_grid(ws_handle *h)
+{
+    const WsDev &d = h->dev;
+    if (h->grid_alloc_cells < d.ncells) {
+        free_grid(h);
+        HIP_TRY(h, hipMalloc(&h->count, (size_t)d.ncells * 4));
+        HIP_TRY(h, hipMalloc(&h->cursor, (size_t)d.ncells * 4));
+        h->grid_alloc_cells = d.ncells;
+    }
+    // start is sized by the guard too, which depends on the dims: always (re)build it
+    hipFree(h->start);
+    hipFree(h->bsum);
+    h->start = h->bsum = nullptr;
+    const size_t nstart = (size_t)d.ncells + 2 * (size_t)d.guard + 2;
+    HIP_TRY(h, hipMalloc(&h->start, nstart * 4));
+    h->nscan_blocks = wsk_scan_blocks(d.ncells);
+    HIP_TRY(h, hipMalloc(&h->bsum, (size_t)h->nscan_blocks * 4));
+    // constant parts of cell_start: front guard = 0, [ncells] and the back guard = n
+    HIP_TRY(h, hipMemsetAsync(h->start, 0, (size_t)d.guard * 4, h->stream));
+    std::vector<uint32_t> tail((size_t)d.guard + 2, d.n);
+    HIP_TRY(h, hipMemcpyAsync(h->start + d.guard + d.ncells, tail.data(), tail.size() * 4, hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->count, 0, (size_t)d.ncells * 4, h->stream));
+    return WS_OK;
+}
+
+ws_status upload_mult(ws_handle *h)
+{
+    uint8_t m[27];
+    bool alias = false;
+    const uint32_t n = h->dev.hash_n;
+    for (int dx = -1; dx <= 1; dx++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dz = -1; dz <= 1; dz++) {
+                uint32_t cnt = 1;
+                if (is_pow2(n)) {
+                    // hash_cell is linear mod N for power-of-two N (the only N the reference's
+                    // sort supports, src/fluid_compute.rs:15): offsets o with hash(o) == hash(delta)
+                    cnt = 0;
+                    const uint32_t hd = ref_hash_delta(dx, dy, dz, n);
+                    for (int ox = -1; ox <= 1; ox++)
+                        for (int oy = -1; oy <= 1; oy++)
+                            for (int oz = -1; oz <= 1; oz++)
+                                if (ref_hash_delta(ox, oy, oz, n) == hd) cnt++;
+                }
+                if (cnt > 1) alias = true;
+                m[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = (uint8_t)cnt;
+            }
+    h->alias = alias;
+    if (!h->mult) HIP_TRY(h, hipMalloc(&h->mult, 32));
+    HIP_TRY(h, hipMemcpy(h->mult, m, 27, hipMemcpyHostToDevice));
+    return WS_OK;
+}
+
+ws_status ensure_stage(ws_handle *h, size_t bytes)
+{
+    if (h->stage_bytes >= bytes) return WS_OK;
+    hipFree(h->stage);
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    HIP_TRY(h, hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    return WS_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------
+hipEvent_t get_event(ws_handle *h)
+{
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct Prof {
+    ws_handle *h;
+    bool on;
+    WsEventPair p{};
+    Prof(ws_handle *h_, uint32_t k) : h(h_), on((h_->flags & WS_FLAG_PROFILE) != 0)
+    {
+        if (!on) return;
+        p.kernel = k;
+        p.a = get_event(h);
+        p.b = get_event(h);
+        hipEventRecord(p.a, h->stream);
+    }
+    ~Prof()
+    {
+        if (!on) return;
+        hipEventRecord(p.b, h->stream);
+        h->pending.push_back(p);
+    }
+};
+
+void drain_profile(ws_handle *h)
+{
+    for (auto &p : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->prof_ms[p.kernel] += ms;
+            h->prof_cnt[p.kernel] += 1;
+        }
+        h->pool.push_back(p.a);
+        h->pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+// Put freshly uploaded `cur` into the "binned" state every ws_step starts from.
+ws_status bin_current(ws_handle *h)
+{
+    HIP_TRY(h, hipMemsetAsync(h->count, 0, (size_t)h->dev.ncells * 4, h->stream));
+    {
+        Prof pr(h, WS_K_BIN);
+        wsk_bin(h->stream, h->dev, h->cur.pred, h->cid_cur, h->count);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return WS_OK;
+}
+
+ws_status upload_positions(ws_handle *h, const float *pos_xyz)
+{
+    const size_t bytes = (size_t)h->n * 12;
+    ws_status st = ensure_stage(h, bytes);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->stage, pos_xyz, bytes, hipMemcpyHostToDevice, h->stream));
+    wsk_upload_positions(h->stream, (const float *)h->stage, h->cur, h->n);
+    HIP_TRY(h, hipGetLastError());
+    st = bin_current(h);
+    if (st) return st;
+    // the caller's buffer must not be referenced after return
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->steps = 0;
+    return WS_OK;
+}
+
+void free_all(ws_handle *h)
+{
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drain_profile(h);
+    for (auto e : h->pool) hipEventDestroy(e);
+    free_grid(h);
+    hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
+    hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
+    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->dens); hipFree(h->accel);
+    hipFree(h->slot_tmp); hipFree(h->mult); hipFree(h->stage);
+    hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
+    hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
+    if (h->done) hipEventDestroy(h->done);
+    if (h->stream) hipStreamDestroy(h->stream);
+}
+
+}  // namespace
+
+// ======================================================================================
+// host-side functions of the path
+// ======================================================================================
+extern "C" {
+
+uint32_t ws_abi_version(void) { return WS_ABI_VERSION; }
+
+const char *ws_status_string(ws_status s)
+{
+    switch (s) {
+        case WS_OK: return "ok";
+        case WS_ERR_INVALID_ARG: return "invalid argument";
+        case WS_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case WS_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case WS_ERR_HIP: return "HIP runtime error";
+        case WS_ERR_COMM: return "RCCL communication error";
+        case WS_ERR_UNSUPPORTED: return "unsupported";
+        case WS_ERR_NOT_READY: return "not ready";
+    }
+    return "unknown status";
+}
+
+const char *ws_kernel_name(uint32_t k)
+{
+    static const char *names[WS_K_COUNT] = {"cell_scan", "cell_scatter", "reorder", "density", "force_integrate_bin",
+                                            "bin"};
+    return k < WS_K_COUNT ? names[k] : "?";
+}
+
+// src/fluid_compute.rs:20-27,:67-79; src/gravity.rs:6,:29-33; src/fluid_container.rs:8-9
+ws_status ws_default_params(ws_params *out)
+{
+    if (!out) return WS_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->delta_time = 1.0f / 60.0f;
+    out->collision_damping = 0.95f;
+    out->smoothing_radius = 0.25f;
+    out->target_density = 10.0f;
+    out->pressure_scalar = 22.0f;
+    out->near_pressure_scalar = 2.0f;
+    out->viscosity_strength = 0.1f;
+    out->gravity[1] = -9.8f;
+    const float position[3] = {0.f, 0.f, 0.f}, size[3] = {16.f, 9.f, 9.f};
+    return ws_get_ext(position, size, 0.1f, out->ext_min, out->ext_max);
+}
+
+// src/fluid_compute.rs:55-63
+ws_status ws_get_smoothing_kernel(const ws_params *p, ws_smoothing_kernel *out)
+{
+    if (!p || !out) return WS_ERR_INVALID_ARG;
+    const float PI = 3.14159265358979323846f;  // std::f32::consts::PI
+    const float h = p->smoothing_radius;
+    out->pow2 = 15.0f / (2.0f * PI * powi_f32(h, 5));
+    out->pow2_der = 15.0f / (PI * powi_f32(h, 5));
+    out->pow3 = 15.0f / (PI * powi_f32(h, 6));
+    out->pow3_der = 45.0f / (PI * powi_f32(h, 6));
+    out->spikey_pow3 = 315.0f / (64.0f * PI * powi_f32(h, 9));
+    return WS_OK;
+}
+
+// src/helpers.rs:3-20
+ws_status ws_cube_fluid(uint32_t ni, uint32_t nj, uint32_t nk, float r, float *out)
+{
+    if (!out) return WS_ERR_INVALID_ARG;
+    const float ox = r - (float)ni * r, oy = r - (float)nj * r, oz = r - (float)nk * r;
+    const float diam = r * 2.0f;
+    size_t o = 0;
+    for (uint32_t i = 0; i < ni; i++)
+        for (uint32_t j = 0; j < nj; j++)
+            for (uint32_t k = 0; k < nk; k++) {
+                out[o++] = (float)i * diam + ox;
+                out[o++] = (float)j * diam + oy;
+                out[o++] = (float)k * diam + oz;
+            }
+    return WS_OK;
+}
+
+// src/fluid_container.rs:42-50
+ws_status ws_get_ext(const float position[3], const float size[3], float padding, float ext_min[4], float ext_max[4])
+{
+    if (!position || !size || !ext_min || !ext_max) return WS_ERR_INVALID_ARG;
+    for (int c = 0; c < 3; c++) {
+        const float half = size[c] / 2.0f;
+        ext_min[c] = (position[c] - half) + padding;
+        ext_max[c] = (position[c] + half) - padding;
+    }
+    ext_min[3] = ext_max[3] = 0.0f;
+    return WS_OK;
+}
+
+// src/fluid_compute.rs:251-273
+uint32_t ws_bit_sorter_stage_count(uint32_t data_length)
+{
+    uint32_t k = 0;
+    uint64_t p = 1;
+    while (p < data_length) {
+        p <<= 1;
+        k++;
+    }
+    return k * (k + 1) / 2;
+}
+
+// ======================================================================================
+// lifetime
+// ======================================================================================
+ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, const ws_device_cfg *cfg,
+                    ws_handle **out)
+{
+    if (!out) return WS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!pos_xyz || n == 0) return fail(nullptr, WS_ERR_INVALID_ARG, "pos_xyz is NULL or n == 0");
+    ws_status st = validate_params(nullptr, params);
+    if (st) return st;
+    if (cfg && cfg->world_size > 1) return fail(nullptr, WS_ERR_UNSUPPORTED, "multi-GPU slabs are created with ws_create_slab");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, WS_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    const int device = cfg ? cfg->device : 0;
+    if (device < 0 || device >= ndev) return fail(nullptr, WS_ERR_NO_DEVICE, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, WS_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, WS_ERR_NO_DEVICE, "device is not gfx950 (kernels are built for MI355X only)");
+
+    ws_handle *h = new (std::nothrow) ws_handle();
+    if (!h) return fail(nullptr, WS_ERR_OUT_OF_MEMORY, "host allocation failed");
+    h->device = device;
+    h->flags = cfg ? cfg->flags : 0;
+    h->n = n;
+    h->params = *params;
+
+    auto bail = [&](ws_status s) {
+        g_create_error = h->err;
+        free_all(h);
+        delete h;
+        return s;
+    };
+#define CREATE_TRY(expr)                  \
+    do {                                  \
+        ws_status s_ = (expr);            \
+        if (s_) return bail(s_);          \
+    } while (0)
+#define CREATE_HIP(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return bail(fail(h, e_ == hipErrorOutOfMemory ? WS_ERR_OUT_OF_MEMORY : WS_ERR_HIP, #expr, e_)); \
+    } while (0)
+
+    CREATE_HIP(hipSetDevice(device));
+    CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
+    CREATE_TRY(derive_dev(h, *params, n, &h->dev));
+    const size_t n16 = (size_t)n * 16;
+    CREATE_HIP(hipMalloc(&h->cur.pos, n16));
+    CREATE_HIP(hipMalloc(&h->cur.vel, n16));
+    CREATE_HIP(hipMalloc(&h->cur.pred, n16));
+    CREATE_HIP(hipMalloc(&h->srt.pos, n16));
+    CREATE_HIP(hipMalloc(&h->srt.vel, n16));
+    CREATE_HIP(hipMalloc(&h->srt.pred, n16));
+    CREATE_HIP(hipMalloc(&h->cid_cur, (size_t)n * 4));
+    CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
+    CREATE_HIP(hipMalloc(&h->dens, (size_t)n * 8));
+    CREATE_HIP(hipMalloc(&h->accel, n16));
+    CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
+    CREATE_TRY(alloc_grid(h));
+    CREATE_TRY(upload_mult(h));
+    CREATE_TRY(upload_positions(h, pos_xyz));
+#undef CREATE_TRY
+#undef CREATE_HIP
+    *out = h;
+    return WS_OK;
+}
+
+ws_status ws_destroy(ws_handle *h)
+{
+    if (!h) return WS_OK;
+    hipSetDevice(h->device);
+    free_all(h);
+    delete h;
+    return WS_OK;
+}
+
+const char *ws_last_error(ws_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+uint32_t ws_num_particles(ws_handle *h) { return h ? h->n : 0; }
+uint64_t ws_steps_done(ws_handle *h) { return h ? h->steps : 0; }
+
+// ======================================================================================
+// per frame
+// ======================================================================================
+ws_status ws_step(ws_handle *h)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const WsDev &d = h->dev;
+    hipStream_t s = h->stream;
+    {
+        Prof p(h, WS_K_SCAN);
+        wsk_scan(s, h->count, h->start + d.guard, h->cursor, h->bsum, d.ncells, h->nscan_blocks, true);
+    }
+    {
+        Prof p(h, WS_K_SCATTER);
+        wsk_scatter(s, h->cid_cur, h->cursor, h->slot_tmp, d.n);
+    }
+    {
+        Prof p(h, WS_K_REORDER);
+        wsk_reorder(s, d, h->slot_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt);
+    }
+    {
+        Prof p(h, WS_K_DENSITY);
+        wsk_density(s, d, h->start, h->cid_srt, h->srt.pred, h->dens, h->mult, h->alias);
+    }
+    {
+        Prof p(h, WS_K_FORCE);
+        wsk_force(s, d, h->start, h->cid_srt, h->srt, h->dens, h->cur, h->accel, h->cid_cur, h->count, h->mult,
+                  h->alias);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->done, s));
+    h->done_recorded = true;
+    h->steps++;
+    return WS_OK;
+}
+
+ws_status ws_ready(ws_handle *h, int *ready)
+{
+    if (!h || !ready) return WS_ERR_INVALID_ARG;
+    if (!h->done_recorded) {
+        *ready = 1;
+        return WS_OK;
+    }
+    const hipError_t e = hipEventQuery(h->done);
+    if (e == hipSuccess)
+        *ready = 1;
+    else if (e == hipErrorNotReady)
+        *ready = 0;
+    else
+        return fail(h, WS_ERR_HIP, "hipEventQuery", e);
+    return WS_OK;
+}
+
+ws_status ws_sync(ws_handle *h)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_profile(h);
+    return WS_OK;
+}
+
+ws_status ws_set_params(ws_handle *h, const ws_params *params)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    ws_status st = validate_params(h, params);
+    if (st) return st;
+    HIP_TRY(h, hipSetDevice(h->device));
+    WsDev nd;
+    st = derive_dev(h, *params, h->n, &nd);
+    if (st) return st;
+    const WsDev &od = h->dev;
+    const bool regrid = memcmp(nd.org, od.org, sizeof nd.org) || memcmp(nd.dim, od.dim, sizeof nd.dim) || nd.h != od.h;
+    h->params = *params;
+    if (!regrid) {
+        h->dev = nd;  // by-value kernel argument: picked up by the next ws_step
+        return WS_OK;
+    }
+    // cell size or container changed: rebuild the grid tables and re-bin the current state
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->dev = nd;
+    st = alloc_grid(h);
+    if (st) return st;
+    return bin_current(h);
+}
+
+ws_status ws_read_positions(ws_handle *h, float *out_xyz)
+{
+    if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n * 12;
+    ws_status st = ensure_stage(h, bytes);
+    if (st) return st;
+    wsk_gather_positions(h->stream, h->cur.pos, (float *)h->stage, h->n);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_xyz, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_profile(h);
+    return WS_OK;
+}
+
+ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
+{
+    if (!h || !out) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
+    ws_status st = ensure_stage(h, bytes);
+    if (st) return st;
+    wsk_gather_particles(h->stream, h->dev, h->cur, h->dens, h->accel, h->steps > 0, (ws_particle80 *)h->stage, h->n);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_profile(h);
+    return WS_OK;
+}
+
+ws_status ws_reset(ws_handle *h, const float *pos_xyz)
+{
+    if (!h || !pos_xyz) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return upload_positions(h, pos_xyz);
+}
+
+ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
+{
+    if (!h || !in) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
+    ws_status st = ensure_stage(h, bytes);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->stage, in, bytes, hipMemcpyHostToDevice, h->stream));
+    wsk_upload_particles(h->stream, (const ws_particle80 *)h->stage, h->cur, h->n);
+    HIP_TRY(h, hipGetLastError());
+    st = bin_current(h);
+    if (st) return st;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->steps = 0;
+    return WS_OK;
+}
+
+// ======================================================================================
+// reference-layout sort view
+// ======================================================================================
+ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, uint32_t *cell_offsets)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint32_t n = h->n;
+    hipStream_t s = h->stream;
+    if (!h->v_keys) {
+        HIP_TRY(h, hipMalloc(&h->v_keys, (size_t)n * 4));
+        HIP_TRY(h, hipMalloc(&h->v_perm, (size_t)n * 4));
+        HIP_TRY(h, hipMalloc(&h->v_tmp, (size_t)n * 4));
+        HIP_TRY(h, hipMalloc(&h->v_count, (size_t)n * 4));
+        HIP_TRY(h, hipMalloc(&h->v_cursor, (size_t)n * 4));
+        HIP_TRY(h, hipMalloc(&h->v_start, ((size_t)n + 1) * 4));
+        HIP_TRY(h, hipMalloc(&h->v_off, (size_t)n * 4));
+        HIP_TRY(h, hipMalloc(&h->v_bsum, (size_t)wsk_scan_blocks(n) * 4));
+        HIP_TRY(h, hipMemcpy(h->v_start + n, &n, 4, hipMemcpyHostToDevice));
+    }
+    if (h->steps == 0) {
+        // src/fluid_compute.rs:306-308: all three buffers start as the identity
+        wsk_iota(s, h->v_keys, n);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipStreamSynchronize(s));
+        for (uint32_t *dst : {keys_by_id, perm, cell_offsets})
+            if (dst) HIP_TRY(h, hipMemcpy(dst, h->v_keys, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return WS_OK;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->v_count, 0, (size_t)n * 4, s));
+    // the predicted positions the last step started from live in the sorted copy
+    wsk_view_keys(s, h->dev, h->srt.pred, h->srt.pos, h->v_keys, h->v_count);
+    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, n, wsk_scan_blocks(n), false);
+    wsk_iota(s, h->v_perm, n);  // scratch: ids in id order as the scatter's input index
+    wsk_scatter(s, h->v_keys, h->v_cursor, h->v_tmp, n);
+    wsk_view_fix(s, h->v_tmp, h->v_keys, h->v_start, h->v_perm, n);
+    wsk_view_offsets(s, h->v_start, h->v_off, n);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (keys_by_id) HIP_TRY(h, hipMemcpy(keys_by_id, h->v_keys, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (perm) HIP_TRY(h, hipMemcpy(perm, h->v_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (cell_offsets) HIP_TRY(h, hipMemcpy(cell_offsets, h->v_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return WS_OK;
+}
+
+// ======================================================================================
+// introspection
+// ======================================================================================
+ws_status ws_profile_read(ws_handle *h, uint32_t k, double *total_ms, uint64_t *launches)
+{
+    if (!h || k >= WS_K_COUNT) return WS_ERR_INVALID_ARG;
+    ws_status st = ws_sync(h);
+    if (st) return st;
+    if (total_ms) *total_ms = h->prof_ms[k];
+    if (launches) *launches = h->prof_cnt[k];
+    return WS_OK;
+}
+
+ws_status ws_profile_reset(ws_handle *h)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    ws_status st = ws_sync(h);
+    if (st) return st;
+    for (int k = 0; k < WS_K_COUNT; k++) {
+        h->prof_ms[k] = 0;
+        h->prof_cnt[k] = 0;
+    }
+    return WS_OK;
+}
+
+ws_status ws_grid_dims(ws_handle *h, uint32_t dims[3])
+{
+    if (!h || !dims) return WS_ERR_INVALID_ARG;
+    for (int c = 0; c < 3; c++) dims[c] = (uint32_t)h->dev.dim[c];
+    return WS_OK;
+}
+
+}  // extern "C"

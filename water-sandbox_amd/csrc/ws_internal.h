@@ -1,0 +1,113 @@
+// ws_internal.h -- shared between the C-ABI host code and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "wsfluid.h"
+
+// Everything a kernel needs besides array pointers; passed by value (kernarg / SGPRs).
+struct WsDev {
+    // FluidStaticProps, src/fluid_compute.rs:41-51
+    float dt, damping, h, target_density, pressure_scalar, near_pressure_scalar, viscosity;
+    // SmoothingKernel, src/fluid_compute.rs:30-38
+    float k_pow2, k_pow2_der, k_pow3, k_pow3_der, k_spikey;
+    float grav[3];
+    float ext_min[3], ext_max[3];
+    // Largest f32 T with sqrtf(T) <= h: `!(d2 > T)` is bit-for-bit the reference's
+    // `!(distance > smoothing_radius)` without taking the square root first.
+    float d2_accept;
+    // dense cell grid over the padded container: cell = floor(pred / h) (simulation.wgsl:121-123)
+    int32_t org[3];  // grid origin in cell coordinates
+    int32_t dim[3];  // cells along x, y, z (z fastest in memory, x slowest)
+    int32_t guard;   // guard entries in front of / behind cell_start
+    uint32_t n;      // particles
+    uint32_t ncells;
+    uint32_t hash_n;  // the reference's `num_particles` in hash_cell (global N)
+};
+
+// SoA particle set (one of two ping-pong copies).
+struct WsSoA {
+    float4 *pos;   // xyz = position, w = particle id (bits)
+    float4 *vel;   // xyz = velocity
+    float4 *pred;  // xyz = predicted_position
+};
+
+struct WsEventPair {
+    uint32_t kernel;
+    hipEvent_t a, b;
+};
+
+struct ws_handle {
+    int device = 0;
+    uint32_t flags = 0;
+    uint32_t n = 0;
+    uint64_t steps = 0;
+    ws_params params{};
+    ws_smoothing_kernel sk{};
+    WsDev dev{};
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool done_recorded = false;
+
+    WsSoA cur{};   // state in the order of the last step (written by the force kernel)
+    WsSoA srt{};   // cell-sorted copy the density/force kernels read
+    uint32_t *cid_cur = nullptr;  // cell id per particle of `cur`
+    uint32_t *cid_srt = nullptr;  // cell id per particle of `srt`
+    float2 *dens = nullptr;       // (density, near density) in `srt` order
+    float4 *accel = nullptr;      // acceleration in `srt` order
+    uint32_t *slot_tmp = nullptr; // particle index per tentative slot
+    uint32_t *count = nullptr;    // per-cell particle count (histogram)
+    uint32_t *cursor = nullptr;   // per-cell fill cursor
+    uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
+    uint32_t *bsum = nullptr;     // scan block sums
+    uint32_t nscan_blocks = 0;
+    uint8_t *mult = nullptr;      // 27 stencil multiplicities (hash aliasing), device
+    bool alias = false;
+    size_t grid_alloc_cells = 0;
+
+    // staging for uploads / readback
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+
+    // reference-layout sort view (lazy)
+    uint32_t *v_keys = nullptr, *v_perm = nullptr, *v_tmp = nullptr, *v_count = nullptr,
+             *v_cursor = nullptr, *v_start = nullptr, *v_bsum = nullptr, *v_off = nullptr;
+
+    // profiling
+    std::vector<WsEventPair> pending;
+    std::vector<hipEvent_t> pool;
+    double prof_ms[WS_K_COUNT] = {0};
+    uint64_t prof_cnt[WS_K_COUNT] = {0};
+
+    std::string err;
+};
+
+// ---- kernel launchers (ws_kernels.hip) -------------------------------------------
+void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32_t n);
+void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);
+void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count);
+void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *bsum,
+              uint32_t nitems, uint32_t nblocks, bool zero_count);
+uint32_t wsk_scan_blocks(uint32_t nitems);
+void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n);
+void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur,
+                 const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt,
+                 const float4 *pred, float2 *dens, const uint8_t *mult, bool alias);
+void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+               const float2 *dens, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count,
+               const uint8_t *mult, bool alias);
+void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float2 *dens, const float4 *accel,
+                          bool have_step, ws_particle80 *out, uint32_t n);
+// reference-layout view
+void wsk_view_keys(hipStream_t s, const WsDev &d, const float4 *pred, const float4 *pos_with_id,
+                   uint32_t *keys_by_id, uint32_t *count);
+void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, const uint32_t *start,
+                  uint32_t *perm, uint32_t n);
+void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
+void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
