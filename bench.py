@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- simulation steps/s of the SPH fluid step on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--dist cloud|lattice]
+
+One "step" = one full pass of the hot path (cell sort -> density -> force -> integrate) over all
+particles, inputs resident in HBM before the timed region, no host readback inside it.  Rank 0
+prints ONE JSON line.  For N > 1 the driver launches this under torch.distributed.run (one rank per
+GPU); see DESIGN.md "Multi-GPU".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic bytes per particle per step, SURVEY.md 8(d): K1 24 + K2 12 + K3 12 + K4 40 + K5 64 + K6 72
+B_ALG = {"K1": 24, "K2": 12, "K3": 12, "K4": 40, "K5": 64, "K6": 72}
+B_ALG_STEP = sum(B_ALG.values())  # 224
+# which reference passes each HIP kernel implements (DESIGN.md "Kernels")
+KERNEL_ALG_BYTES = {
+    "cell_scan": 0,
+    "cell_scatter": B_ALG["K2"],
+    "reorder": B_ALG["K3"],
+    "density": B_ALG["K4"],
+    "force_integrate_bin": B_ALG["K5"] + B_ALG["K6"] + B_ALG["K1"],
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3", help="c1..c5 | ref (BASELINE.md section 2)")
+    ap.add_argument("--dist", default="cloud", choices=["cloud", "lattice"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(pos, params, steps):
+    """The CPU restatement of the reference WGSL (oracle, 'fast' sort mode, OpenMP) timed on
+    this host on the SAME workload for a few steps.  Reported, never the target."""
+    from oracle import oracle as O
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import oracle_from_params
+
+    orc = oracle_from_params(O, pos, params)
+    orc.step(O.SORT_FAST)  # warm-up (page faults, thread team)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.step(O.SORT_FAST)
+    dt = time.perf_counter() - t0
+    return {
+        "value": steps / dt,
+        "unit": "steps/s",
+        "cores": O.default_threads(),
+        "kind": "port",
+        "sample": "%d full steps of the same %d-particle workload after 1 warm-up step (oracle, fast sort mode)"
+        % (steps, orc.n),
+    }
+
+
+def load_traffic(config, dist):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
+    (profiles/traffic.json), or None if no measurement for this workload is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get("%s-%s" % (config, dist), {}).get("force_integrate_bin_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    import water_sandbox_amd as ws
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+
+    pos, params = ws.workloads.make_workload(args.config, args.dist)
+    n = pos.shape[0]
+    worker = ws.FluidWorker(pos, params, device=local_rank, profile=True)
+    force_id = ws.fluid.KERNEL_IDS["force_integrate_bin"]
+
+    def barrier():
+        worker.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+
+    worker.profile_select(1 << force_id)  # timed region: events around the dominant kernel only
+    worker.run(args.warmup)
+    barrier()
+    worker.profile_reset()
+    t0 = time.perf_counter()
+    worker.run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = worker.profile()
+    force_ms, force_cnt = prof["force_integrate_bin"]
+
+    breakdown = None
+    if rank == 0:
+        # per-kernel breakdown from a short separate pass (all kernels bracketed by events)
+        worker.profile_select(0xFFFFFFFF)
+        worker.profile_reset()
+        worker.run(min(args.steps, 20))
+        worker.sync()
+        breakdown = {k: (v[0] / max(v[1], 1)) for k, v in worker.profile().items() if v[1]}
+
+    if rank == 0:
+        steps_per_s = args.steps / elapsed
+        force_avg_s = force_ms / max(force_cnt, 1) * 1e-3
+        alg_bytes = KERNEL_ALG_BYTES["force_integrate_bin"] * n
+        achieved = alg_bytes / force_avg_s / 1e9
+        out = {
+            "metric": "simulation steps/sec @ N particles",
+            "value": steps_per_s,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d particles, 3D, %s, reference default parameters"
+                % (args.config.upper(), n * world, "uniform cloud seed 0x%X" % ws.workloads.cloud_seed(args.config)
+                   if args.dist == "cloud" else "cube_fluid lattice"),
+                "particles": n * world,
+                "distribution": args.dist,
+                "container": [params.ext_min[i] for i in range(3)] + [params.ext_max[i] for i in range(3)],
+                "grid_cells": list(worker.grid_dims()),
+                "readback_in_timed_region": False,
+            },
+            "particle_steps_per_s": steps_per_s * n * world,
+            "algorithmic_GBps_step": B_ALG_STEP * n * world * steps_per_s / 1e9,
+            "roofline": {
+                "kernel": "force_integrate_bin (K5 update_pressure_force + K6 integrate + next K1 binning)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(args.config, args.dist),
+                "alg_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": force_avg_s * 1e3,
+                "launches_timed": force_cnt,
+            },
+            "kernel_ms": breakdown,
+            "stats": worker.stats(),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pos, params, args.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        if args.breakdown:
+            for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]):
+                print("%-22s %9.3f ms" % (k, v), file=sys.stderr)
+        print(json.dumps(out))
+    worker.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -197,6 +197,12 @@ const char *ws_kernel_name(uint32_t kernel_id);
  * for enqueued steps. */
 ws_status ws_profile_read(ws_handle *h, uint32_t kernel_id, double *total_ms, uint64_t *launches);
 ws_status ws_profile_reset(ws_handle *h);
+/* Restrict WS_FLAG_PROFILE's events to the kernel ids whose bit is set in mask (default: all),
+ * so that a timed region carries two events per step instead of two per kernel. */
+ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
+/* Cumulative device-side counters: out[0] / out[1] = density / force workgroup tiles whose
+ * candidate ranges overflowed LDS and took the direct-from-global path; the rest reserved. */
+ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding). */
 ws_status ws_grid_dims(ws_handle *h, uint32_t dims[3]);
 

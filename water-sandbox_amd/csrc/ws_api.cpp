@@ -4,6 +4,7 @@
 // AppComputeWorker plays in the reference (src/fluid_compute.rs:277-366,:393-397).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -223,7 +224,7 @@ struct Prof {
     ws_handle *h;
     bool on;
     WsEventPair p{};
-    Prof(ws_handle *h_, uint32_t k) : h(h_), on((h_->flags & WS_FLAG_PROFILE) != 0)
+    Prof(ws_handle *h_, uint32_t k) : h(h_), on((h_->flags & WS_FLAG_PROFILE) != 0 && ((h_->prof_mask >> k) & 1u))
     {
         if (!on) return;
         p.kernel = k;
@@ -289,8 +290,8 @@ void free_all(ws_handle *h)
     free_grid(h);
     hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
     hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
-    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->dens); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->mult); hipFree(h->stage);
+    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->rho); hipFree(h->accel);
+    hipFree(h->slot_tmp); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
     if (h->done) hipEventDestroy(h->done);
@@ -430,6 +431,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     h->flags = cfg ? cfg->flags : 0;
     h->n = n;
     h->params = *params;
+    if (const char *v = getenv("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : WS_VARIANT_TILED;
 
     auto bail = [&](ws_status s) {
         g_create_error = h->err;
@@ -462,9 +464,11 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->srt.pred, n16));
     CREATE_HIP(hipMalloc(&h->cid_cur, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
-    CREATE_HIP(hipMalloc(&h->dens, (size_t)n * 8));
+    CREATE_HIP(hipMalloc(&h->rho, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
+    CREATE_HIP(hipMalloc(&h->stats, 64));
+    CREATE_HIP(hipMemset(h->stats, 0, 64));
     CREATE_TRY(alloc_grid(h));
     CREATE_TRY(upload_mult(h));
     CREATE_TRY(upload_positions(h, pos_xyz));
@@ -510,12 +514,12 @@ ws_status ws_step(ws_handle *h)
     }
     {
         Prof p(h, WS_K_DENSITY);
-        wsk_density(s, d, h->start, h->cid_srt, h->srt.pred, h->dens, h->mult, h->alias);
+        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->rho, h->mult, h->alias, h->variant, h->stats);
     }
     {
         Prof p(h, WS_K_FORCE);
-        wsk_force(s, d, h->start, h->cid_srt, h->srt, h->dens, h->cur, h->accel, h->cid_cur, h->count, h->mult,
-                  h->alias);
+        wsk_force(s, d, h->start, h->cid_srt, h->srt, h->rho, h->cur, h->accel, h->cid_cur, h->count, h->mult,
+                  h->alias, h->variant, h->stats);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));
@@ -596,7 +600,8 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
-    wsk_gather_particles(h->stream, h->dev, h->cur, h->dens, h->accel, h->steps > 0, (ws_particle80 *)h->stage, h->n);
+    wsk_gather_particles(h->stream, h->dev, h->cur, h->rho, h->srt.vel, h->accel, h->steps > 0,
+                         (ws_particle80 *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -695,6 +700,22 @@ ws_status ws_profile_reset(ws_handle *h)
         h->prof_ms[k] = 0;
         h->prof_cnt[k] = 0;
     }
+    return WS_OK;
+}
+
+ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    h->prof_mask = kernel_mask;
+    return WS_OK;
+}
+
+ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
+{
+    if (!h || !out) return WS_ERR_INVALID_ARG;
+    ws_status st = ws_sync(h);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpy(out, h->stats, 64, hipMemcpyDeviceToHost));
     return WS_OK;
 }
 

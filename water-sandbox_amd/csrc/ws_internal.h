@@ -29,10 +29,13 @@ struct WsDev {
     uint32_t hash_n;  // the reference's `num_particles` in hash_cell (global N)
 };
 
+// density / force kernel family (WS_VARIANT=simple|tiled in the environment, for A/B tests)
+enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_TILED = 1 };
+
 // SoA particle set (one of two ping-pong copies).
 struct WsSoA {
     float4 *pos;   // xyz = position, w = particle id (bits)
-    float4 *vel;   // xyz = velocity
+    float4 *vel;   // xyz = velocity (sorted copy: w = near density after K4)
     float4 *pred;  // xyz = predicted_position
 };
 
@@ -44,6 +47,7 @@ struct WsEventPair {
 struct ws_handle {
     int device = 0;
     uint32_t flags = 0;
+    uint32_t prof_mask = 0xFFFFFFFFu;
     uint32_t n = 0;
     uint64_t steps = 0;
     ws_params params{};
@@ -57,7 +61,8 @@ struct ws_handle {
     WsSoA srt{};   // cell-sorted copy the density/force kernels read
     uint32_t *cid_cur = nullptr;  // cell id per particle of `cur`
     uint32_t *cid_srt = nullptr;  // cell id per particle of `srt`
-    float2 *dens = nullptr;       // (density, near density) in `srt` order
+    float *rho = nullptr;         // density in `srt` order (near density rides in srt.vel[i].w)
+    int variant = WS_VARIANT_TILED;
     float4 *accel = nullptr;      // acceleration in `srt` order
     uint32_t *slot_tmp = nullptr; // particle index per tentative slot
     uint32_t *count = nullptr;    // per-cell particle count (histogram)
@@ -65,6 +70,7 @@ struct ws_handle {
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
     uint32_t *bsum = nullptr;     // scan block sums
     uint32_t nscan_blocks = 0;
+    uint32_t *stats = nullptr;    // device counters: [0]/[1] density/force tiles that overflowed LDS
     uint8_t *mult = nullptr;      // 27 stencil multiplicities (hash aliasing), device
     bool alias = false;
     size_t grid_alloc_cells = 0;
@@ -96,14 +102,14 @@ uint32_t wsk_scan_blocks(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur,
                  const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt,
-                 const float4 *pred, float2 *dens, const uint8_t *mult, bool alias);
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, float *rho,
+                 const uint8_t *mult, bool alias, int variant, uint32_t *stats);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-               const float2 *dens, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count,
-               const uint8_t *mult, bool alias);
+               const float *rho, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult,
+               bool alias, int variant, uint32_t *stats);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
-void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float2 *dens, const float4 *accel,
-                          bool have_step, ws_particle80 *out, uint32_t n);
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float *rho, const float4 *srt_vel,
+                          const float4 *accel, bool have_step, ws_particle80 *out, uint32_t n);
 // reference-layout view
 void wsk_view_keys(hipStream_t s, const WsDev &d, const float4 *pred, const float4 *pos_with_id,
                    uint32_t *keys_by_id, uint32_t *count);

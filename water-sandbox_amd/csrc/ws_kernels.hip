@@ -10,6 +10,8 @@
 // each operation is one IEEE binary32 operation (hipcc's default f32 divide and sqrt
 // are correctly rounded).  What differs from the reference is only the ORDER in which
 // neighbours are visited (dense-grid order instead of hashed-bucket order).
+#include <type_traits>
+
 #include "ws_internal.h"
 
 #pragma clang fp contract(off)
@@ -306,136 +308,83 @@ __device__ __forceinline__ uint32_t alias_mult(const WsDev &d, const uint8_t *__
 }
 
 // ---------------------------------------------------------------------------------
-// K4 update_density, assets/simulation.wgsl:143-195
+// per-pair arithmetic of K4 / K5, shared by the tiled and the simple kernels.
+// `o` = own predicted position, `q` = neighbour's; d2 has already passed the radius test.
 // ---------------------------------------------------------------------------------
-template <bool ALIAS>
-__global__ void __launch_bounds__(WS_BLOCK) k_density(WsDev d, const uint32_t *__restrict__ start,
-                                                      const uint32_t *__restrict__ cid_srt,
-                                                      const float4 *__restrict__ pred, float2 *__restrict__ dens,
-                                                      const uint8_t *__restrict__ mult)
+
+// simulation.wgsl:176-183
+__device__ __forceinline__ void density_pair(const WsDev &d, float d2, float &density, float &near_density,
+                                             uint32_t mult)
 {
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
-    const float4 o = pred[i];
-    const int c = (int)cid_srt[i];
-    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    float density = 0.f, near_density = 0.f;
-    for (int dx = -1; dx <= 1; dx++) {
-        for (int dy = -1; dy <= 1; dy++) {
-            const int cc = d.guard + c + dx * rowy + dy * rowz;
-            const uint32_t b = start[cc - 1], e = start[cc + 2];
-            for (uint32_t j = b; j < e; j++) {
-                const float4 q = pred[j];
-                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-                const float d2 = ex * ex + ey * ey + ez * ez;
-                if (d2 > d.d2_accept) continue;
-                const float dst = sqrtf(d2);
-                const float w = sk_density(d, dst), wn = sk_near(d, dst);
-                if (ALIAS) {
-                    const uint32_t m = alias_mult(d, mult, o, q);
-                    for (uint32_t r = 0; r < m; r++) {
-                        density += w;
-                        near_density += wn;
-                    }
-                } else {
-                    density += w;
-                    near_density += wn;
-                }
-            }
-        }
+    const float dst = sqrtf(d2);
+    const float w = sk_density(d, dst), wn = sk_near(d, dst);
+    for (uint32_t r = 0; r < mult; r++) {
+        density += w;
+        near_density += wn;
     }
+}
+
+struct ForceAcc {
+    float pfx, pfy, pfz, vfx, vfy, vfz;
+};
+
+// simulation.wgsl:238-263.  nrho = (density, near density) of the neighbour; pressures are
+// recomputed from them (simulation.wgsl:192-193: the same two IEEE operations K4 stored).
+__device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, float ez, float d2, float nrho_x,
+                                           float nrho_y, float4 nvel, float4 vel, float pressure, float near_pressure,
+                                           ForceAcc &a, uint32_t mult)
+{
+    const float dst = sqrtf(d2);
+    if (dst > 0.f) {
+        ex = ex / dst;
+        ey = ey / dst;
+        ez = ez / dst;
+    } else {
+        ex = 0.f;
+        ey = 1.f;
+        ez = 0.f;
+    }
+    const float npress = d.pressure_scalar * (nrho_x - d.target_density);
+    const float nnear = d.near_pressure_scalar * nrho_y;
+    const float slope = sk_der(d, dst);
+    const float shared = (pressure + npress) / 2.f;
+    const float slope_near = sk_der_near(d, dst);
+    const float shared_near = (near_pressure + nnear) / 2.f;
+    const float ax = ex * shared * slope / nrho_x, ay = ey * shared * slope / nrho_x, az = ez * shared * slope / nrho_x;
+    const float bx = ex * shared_near * slope_near / nrho_y, by = ey * shared_near * slope_near / nrho_y,
+                bz = ez * shared_near * slope_near / nrho_y;
+    const float visc = sk_visc(d, dst);
+    const float wx = (nvel.x - vel.x) * visc, wy = (nvel.y - vel.y) * visc, wz = (nvel.z - vel.z) * visc;
+    for (uint32_t r = 0; r < mult; r++) {
+        a.pfx += ax; a.pfy += ay; a.pfz += az;
+        a.pfx += bx; a.pfy += by; a.pfz += bz;
+        a.vfx += wx; a.vfy += wy; a.vfz += wz;
+    }
+}
+
+// K4 epilogue (simulation.wgsl:186-194): density goes to rho[i], near density rides in the
+// unused w lane of the sorted velocity (nobody reads velocities during K4).
+__device__ __forceinline__ void density_store(float density, float near_density, uint32_t i, float *__restrict__ rho,
+                                              float4 *__restrict__ vel)
+{
     density = density + 0.00001f;  // DENSITY_PADDING, simulation.wgsl:4,187-188
     near_density = near_density + 0.00001f;
-    dens[i] = make_float2(density, near_density);
+    rho[i] = density;
+    reinterpret_cast<float *>(vel + i)[3] = near_density;
 }
 
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt,
-                 const float4 *pred, float2 *dens, const uint8_t *mult, bool alias)
+// K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
+__device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const ForceAcc &a, float rho_x, float4 vel,
+                                                          uint32_t i, const float4 *__restrict__ pos, WsSoA out,
+                                                          float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                                          uint32_t *__restrict__ count)
 {
-    if (alias)
-        hipLaunchKernelGGL(k_density<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt, pred,
-                           dens, mult);
-    else
-        hipLaunchKernelGGL(k_density<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt, pred,
-                           dens, mult);
-}
-
-// ---------------------------------------------------------------------------------
-// K5 update_pressure_force (simulation.wgsl:197-269) + K6 integrate (:271-310) +
-// next step's K1 cell binning, fused: one pass over the sorted particles.
-// Reads the sorted copy, writes the ping-pong copy in the same order.
-// ---------------------------------------------------------------------------------
-template <bool ALIAS>
-__global__ void __launch_bounds__(WS_BLOCK) k_force(WsDev d, const uint32_t *__restrict__ start,
-                                                    const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                    const float2 *__restrict__ dens, WsSoA out,
-                                                    float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                    uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
-{
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
-    const float4 o = srt.pred[i];
-    const float4 vel = srt.vel[i];
-    const float2 rho = dens[i];
-    // pressure from density, simulation.wgsl:192-193 (recomputed: same two IEEE ops)
-    const float pressure = d.pressure_scalar * (rho.x - d.target_density);
-    const float near_pressure = d.near_pressure_scalar * rho.y;
-    const int c = (int)cid_srt[i];
-    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-
-    float pfx = 0.f, pfy = 0.f, pfz = 0.f, vfx = 0.f, vfy = 0.f, vfz = 0.f;
-    for (int dx = -1; dx <= 1; dx++) {
-        for (int dy = -1; dy <= 1; dy++) {
-            const int cc = d.guard + c + dx * rowy + dy * rowz;
-            const uint32_t b = start[cc - 1], e = start[cc + 2];
-            for (uint32_t j = b; j < e; j++) {
-                if (j == i) continue;  // `particle_index == neighbour_index`, :232
-                const float4 q = srt.pred[j];
-                float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-                const float d2 = ex * ex + ey * ey + ez * ez;
-                if (d2 > d.d2_accept) continue;
-                const float dst = sqrtf(d2);
-                if (dst > 0.f) {
-                    ex = ex / dst;
-                    ey = ey / dst;
-                    ez = ez / dst;
-                } else {
-                    ex = 0.f;
-                    ey = 1.f;
-                    ez = 0.f;
-                }
-                const float2 nrho = dens[j];
-                const float4 nvel = srt.vel[j];
-                const float npress = d.pressure_scalar * (nrho.x - d.target_density);
-                const float nnear = d.near_pressure_scalar * nrho.y;
-                const float slope = sk_der(d, dst);
-                const float shared = (pressure + npress) / 2.f;
-                const float slope_near = sk_der_near(d, dst);
-                const float shared_near = (near_pressure + nnear) / 2.f;
-                const float ax = ex * shared * slope / nrho.x, ay = ey * shared * slope / nrho.x,
-                            az = ez * shared * slope / nrho.x;
-                const float bx = ex * shared_near * slope_near / nrho.y, by = ey * shared_near * slope_near / nrho.y,
-                            bz = ez * shared_near * slope_near / nrho.y;
-                const float visc = sk_visc(d, dst);
-                const float wx = (nvel.x - vel.x) * visc, wy = (nvel.y - vel.y) * visc, wz = (nvel.z - vel.z) * visc;
-                uint32_t m = 1;
-                if (ALIAS) m = alias_mult(d, mult, o, q);
-                for (uint32_t r = 0; r < m; r++) {
-                    pfx += ax; pfy += ay; pfz += az;
-                    pfx += bx; pfy += by; pfz += bz;
-                    vfx += wx; vfy += wy; vfz += wz;
-                }
-            }
-        }
-    }
-    // simulation.wgsl:265-268
-    const float accx = pfx / rho.x + vfx * d.viscosity;
-    const float accy = pfy / rho.x + vfy * d.viscosity;
-    const float accz = pfz / rho.x + vfz * d.viscosity;
+    const float accx = a.pfx / rho_x + a.vfx * d.viscosity;
+    const float accy = a.pfy / rho_x + a.vfy * d.viscosity;
+    const float accz = a.pfz / rho_x + a.vfz * d.viscosity;
     accel[i] = make_float4(accx, accy, accz, 0.f);
 
-    // K6 integrate, simulation.wgsl:279-309
-    const float4 p0 = srt.pos[i];
+    const float4 p0 = pos[i];
     float vx = vel.x + (d.grav[0] + accx) * d.dt;
     float vy = vel.y + (d.grav[1] + accy) * d.dt;
     float vz = vel.z + (d.grav[2] + accz) * d.dt;
@@ -458,16 +407,461 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force(WsDev d, const uint32_t *__r
     atomicAdd(&count[nc], 1u);
 }
 
-void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-               const float2 *dens, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count,
-               const uint8_t *mult, bool alias)
+// ---------------------------------------------------------------------------------
+// direct candidate walks: one lane, candidates straight from global memory, for the dx
+// planes [P0, P1).  Used by the simple kernels (all three planes), when the reference's
+// hashed table would alias inside one stencil (tiny N: multiplicity table), and as the
+// per-plane fallback of a tile whose candidates do not fit in LDS.
+// ---------------------------------------------------------------------------------
+template <bool ALIAS>
+__device__ __forceinline__ void density_direct(const WsDev &d, const uint32_t *__restrict__ start, int c, float4 o,
+                                               const float4 *__restrict__ pred, const uint8_t *__restrict__ mult,
+                                               float &density, float &near_density, int p0 = 0, int p1 = 3)
 {
-    if (alias)
-        hipLaunchKernelGGL(k_force<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt, srt, dens,
-                           out, accel, cid_out, count, mult);
-    else
-        hipLaunchKernelGGL(k_force<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt, srt,
-                           dens, out, accel, cid_out, count, mult);
+    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    for (int dx = p0 - 1; dx < p1 - 1; dx++) {
+        for (int dy = -1; dy <= 1; dy++) {
+            const int cc = d.guard + c + dx * rowy + dy * rowz;
+            const uint32_t b = start[cc - 1], e = start[cc + 2];
+            for (uint32_t j = b; j < e; j++) {
+                const float4 q = pred[j];
+                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+                const float d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 > d.d2_accept) continue;
+                density_pair(d, d2, density, near_density, ALIAS ? alias_mult(d, mult, o, q) : 1u);
+            }
+        }
+    }
+}
+
+template <bool ALIAS>
+__device__ __forceinline__ void force_direct(const WsDev &d, const uint32_t *__restrict__ start, int c, uint32_t i,
+                                             float4 o, float4 vel, float pressure, float near_pressure,
+                                             const float4 *__restrict__ pred, const float4 *__restrict__ velarr,
+                                             const float *__restrict__ rho, const uint8_t *__restrict__ mult,
+                                             ForceAcc &acc, int p0 = 0, int p1 = 3)
+{
+    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    for (int dx = p0 - 1; dx < p1 - 1; dx++) {
+        for (int dy = -1; dy <= 1; dy++) {
+            const int cc = d.guard + c + dx * rowy + dy * rowz;
+            const uint32_t b = start[cc - 1], e = start[cc + 2];
+            for (uint32_t j = b; j < e; j++) {
+                if (j == i) continue;  // `particle_index == neighbour_index`, simulation.wgsl:232
+                const float4 q = pred[j];
+                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+                const float d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 > d.d2_accept) continue;
+                const float4 nvel = velarr[j];
+                force_pair(d, ex, ey, ez, d2, rho[j], nvel.w, nvel, vel, pressure, near_pressure, acc,
+                           ALIAS ? alias_mult(d, mult, o, q) : 1u);
+            }
+        }
+    }
+}
+
+template <bool ALIAS>
+__global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint32_t *__restrict__ start,
+                                                             const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                             float *__restrict__ rho, const uint8_t *__restrict__ mult)
+{
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.n) return;
+    float density = 0.f, near_density = 0.f;
+    density_direct<ALIAS>(d, start, (int)cid_srt[i], srt.pred[i], srt.pred, mult, density, near_density);
+    density_store(density, near_density, i, rho, srt.vel);
+}
+
+template <bool ALIAS>
+__global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32_t *__restrict__ start,
+                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                           const float *__restrict__ rho, WsSoA out,
+                                                           float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                                           uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
+{
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.n) return;
+    const float4 o = srt.pred[i];
+    const float4 vel = srt.vel[i];  // w = own near density
+    const float rho_x = rho[i];
+    const float pressure = d.pressure_scalar * (rho_x - d.target_density);
+    const float near_pressure = d.near_pressure_scalar * vel.w;
+    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    force_direct<ALIAS>(d, start, (int)cid_srt[i], i, o, vel, pressure, near_pressure, srt.pred, srt.vel, rho, mult,
+                        acc);
+    force_store_integrate_bin(d, acc, rho_x, vel, i, srt.pos, out, accel, cid_out, count);
+}
+
+// ---------------------------------------------------------------------------------
+// tiled kernels: the MI355X form of K4 / K5.
+//
+// A workgroup owns NB_P consecutive particles of the cell-sorted order; their cells span
+// [c_lo, c_hi].  z is the fastest grid axis and y the next, so
+//   * for one (dx,dy) column offset the candidates of ALL of them are one contiguous particle
+//     range  [start[c_lo + s - 1], start[c_hi + s + 2]),  s = (dx*ny + dy)*nz   ("column" range);
+//   * for one dx plane the three column ranges lie inside one contiguous range
+//     [start[c_lo + dx*ny*nz - nz - 1], start[c_hi + dx*ny*nz + nz + 2])        ("merged" range),
+//     which is SMALLER than the three column ranges together when the tile spans several
+//     z-rows (sparse fluid) and larger when it sits inside one dense row.
+// Per plane the workgroup stages whichever is smaller (coalesced 16-B loads) into LDS, so every
+// candidate read of the hot loop is a ds_read_b128: all 3 planes at once if they fit (mode A),
+// else plane by plane (mode B); a plane that alone overflows LDS is walked from global memory.
+// Phase 1: each lane walks its runs (bounds in registers) doing ONLY the radius test and pushes
+// the LDS index of each accepted neighbour onto a per-lane list in LDS ([slot][lane] layout,
+// conflict-free).  Phase 2: the expensive pair arithmetic (sqrt, IEEE divides) runs over the
+// compacted list, i.e. on the ~15 % of candidates that pass.  When a list fills up the wave
+// flushes it through phase 2 and phase 1 resumes where it stopped, so any density works.
+// Every mode visits neighbours in (dx, dy, z, slot) order = the simple kernels' order, so all
+// paths give bit-identical sums.
+// ---------------------------------------------------------------------------------
+#define NB_P 512           // particles (= threads) per workgroup: 8 waves
+#define NB_K 16            // neighbour-list fill level that triggers a flush
+#define NB_ROWS (NB_K + 1) // list rows: the 2-wide test may push one entry past NB_K
+#define NB_CAP 3968        // staged candidates per workgroup (float4 each)
+#define NB_ALIGN 32        // each staged range starts on a multiple of this
+#define NB_TAB (NB_CAP / NB_ALIGN)
+#define NB_LDS_BYTES (NB_CAP * 16 + NB_ROWS * NB_P * 2 + NB_TAB * 4)  // 81 392 B: 2 workgroups / CU
+
+struct NbTile {
+    float4 *sm;       // [NB_CAP] staged {pred.xyz, w}
+    uint16_t *list;   // [NB_ROWS][NB_P]
+    int32_t *tab;     // [NB_TAB] (global index - LDS index) of the range covering each 32-slot group
+};
+
+__device__ __forceinline__ NbTile nb_carve(char *smem)
+{
+    NbTile t;
+    t.sm = reinterpret_cast<float4 *>(smem);
+    t.list = reinterpret_cast<uint16_t *>(smem + NB_CAP * 16);
+    t.tab = reinterpret_cast<int32_t *>(smem + NB_CAP * 16 + NB_ROWS * NB_P * 2);
+    return t;
+}
+
+// XCD-aware workgroup -> tile map: workgroups are dealt round-robin over the 8 XCDs, so
+// giving XCD x the x-th contiguous eighth of the tiles keeps each XCD's L2 on one x-slab
+// of the sorted particles (plus its halo planes) instead of all of them.  Speed only.
+__device__ __forceinline__ uint32_t nb_tile_index(uint32_t ntiles)
+{
+    const uint32_t per = (ntiles + 7u) >> 3;
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+
+__device__ __forceinline__ uint32_t nb_align(uint32_t x) { return (x + (NB_ALIGN - 1)) & ~(uint32_t)(NB_ALIGN - 1); }
+
+// workgroup-uniform geometry of a tile (everything here lives in SGPRs)
+struct NbGeo {
+    int c_lo, c_hi, rowz, rowy, guard;
+};
+
+__device__ __forceinline__ void nb_merged(const NbGeo &g, const uint32_t *__restrict__ start, int p, uint32_t &g0,
+                                          uint32_t &len)
+{
+    const int s = (p - 1) * g.rowy;
+    g0 = start[g.guard + g.c_lo + s - g.rowz - 1];
+    len = start[g.guard + g.c_hi + s + g.rowz + 2] - g0;
+}
+
+__device__ __forceinline__ void nb_column(const NbGeo &g, const uint32_t *__restrict__ start, int p, int dy, uint32_t &g0,
+                                          uint32_t &len)
+{
+    const int s = (p - 1) * g.rowy + dy * g.rowz;
+    g0 = start[g.guard + g.c_lo + s - 1];
+    len = start[g.guard + g.c_hi + s + 2] - g0;
+}
+
+// LDS slots plane p needs, and whether the merged form is the smaller one
+__device__ __forceinline__ uint32_t nb_plane_cost(const NbGeo &g, const uint32_t *__restrict__ start, int p, bool &merged)
+{
+    uint32_t g0, len, cm, cs = 0;
+    nb_merged(g, start, p, g0, len);
+    cm = nb_align(len);
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+        nb_column(g, start, p, dy, g0, len);
+        cs += nb_align(len);
+    }
+    merged = cm <= cs;
+    return merged ? cm : cs;
+}
+
+// a lane's three runs in one plane, each packed as (first LDS index) | (one past last) << 16
+struct NbPlaneRuns {
+    uint32_t a, b, c;
+};
+
+// Stage plane p (workgroup-uniform, may be a run-time value) at LDS slot `used` (advanced) and
+// return this lane's runs in it.  WITH_RHO fills the staged w lane with the candidate's density
+// and builds the LDS -> global index table (K5).  No barrier here.
+template <bool WITH_RHO>
+__device__ __forceinline__ NbPlaneRuns nb_stage_plane(const NbTile &t, const NbGeo &g, int p, bool merged,
+                                                      uint32_t &used, const uint32_t *__restrict__ start, uint32_t i,
+                                                      bool valid, int c, const float4 *__restrict__ pred,
+                                                      const float *__restrict__ rho, uint32_t &self_l)
+{
+    uint32_t sg0[3], sl0[3];  // per column: first global particle / first LDS slot of its range
+    auto stage_range = [&](uint32_t g0, uint32_t len, uint32_t l0) {
+        for (uint32_t k = threadIdx.x; k < len; k += NB_P) {
+            float4 q = pred[g0 + k];
+            if (WITH_RHO) q.w = rho[g0 + k];
+            t.sm[l0 + k] = q;
+        }
+        if (WITH_RHO) {
+            const uint32_t groups = nb_align(len) / NB_ALIGN;
+            if (threadIdx.x < groups) t.tab[l0 / NB_ALIGN + threadIdx.x] = (int32_t)(g0 - l0);
+        }
+    };
+    if (merged) {
+        uint32_t g0, len;
+        nb_merged(g, start, p, g0, len);
+        sg0[0] = sg0[1] = sg0[2] = g0;
+        sl0[0] = sl0[1] = sl0[2] = used;
+        stage_range(g0, len, used);
+        used += nb_align(len);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint32_t len;
+            nb_column(g, start, p, k - 1, sg0[k], len);
+            sl0[k] = used;
+            stage_range(sg0[k], len, used);
+            used += nb_align(len);
+        }
+    }
+    uint32_t r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int s = (p - 1) * g.rowy + (k - 1) * g.rowz;
+        uint32_t b = 0, e = 0;
+        if (valid) {
+            b = start[g.guard + c + s - 1] - sg0[k] + sl0[k];
+            e = start[g.guard + c + s + 2] - sg0[k] + sl0[k];
+        }
+        r[k] = b | (e << 16);
+    }
+    if (p == 1) self_l = i - sg0[1] + sl0[1];  // column (dx,dy) = (0,0) holds the lane's own cell
+    NbPlaneRuns R = {r[0], r[1], r[2]};
+    return R;
+}
+
+// The tile driver shared by K4 and K5.
+//   phase2(cnt)     consumes the lane's list (cnt entries, in visit order)
+//   direct(p0, p1)  walks planes [p0, p1) straight from global memory
+// Phase 1 sees a lane's three runs of one plane as ONE virtual index range [0, T): the LDS
+// address of virtual index v is v + o_k with k picked by two compares, so the hot loop is a
+// plain counted loop (two candidates per trip for ILP) with no run-hopping control flow.
+template <bool WITH_RHO, bool SKIP_SELF, class Phase2, class Direct>
+__device__ __forceinline__ void nb_tile_run(const WsDev &d, const NbTile &t, const uint32_t *__restrict__ start,
+                                            const uint32_t *__restrict__ cid_srt, uint32_t i0, uint32_t i, bool valid,
+                                            int c, float4 o, const float4 *__restrict__ pred,
+                                            const float *__restrict__ rho, uint32_t *__restrict__ stats, int stat_base,
+                                            Phase2 &&phase2, Direct &&direct)
+{
+    NbGeo g;
+    g.c_lo = (int)cid_srt[i0];  // workgroup-uniform: scalar loads
+    g.c_hi = (int)cid_srt[min(i0 + NB_P, d.n) - 1u];
+    g.rowz = d.dim[2];
+    g.rowy = d.dim[1] * d.dim[2];
+    g.guard = d.guard;
+    bool m0, m1, m2;
+    const uint32_t c0 = nb_plane_cost(g, start, 0, m0), c1 = nb_plane_cost(g, start, 1, m1),
+                   c2 = nb_plane_cost(g, start, 2, m2);
+    const bool mode_a = c0 + c1 + c2 <= NB_CAP;  // everything staged at once
+    NbPlaneRuns R0 = {0, 0, 0}, R1 = {0, 0, 0}, R2 = {0, 0, 0};
+    uint32_t self_l = 0, used = 0;
+    bool lds_busy = false;
+    if (mode_a) {
+        R0 = nb_stage_plane<WITH_RHO>(t, g, 0, m0, used, start, i, valid, c, pred, rho, self_l);
+        R1 = nb_stage_plane<WITH_RHO>(t, g, 1, m1, used, start, i, valid, c, pred, rho, self_l);
+        R2 = nb_stage_plane<WITH_RHO>(t, g, 2, m2, used, start, i, valid, c, pred, rho, self_l);
+        __syncthreads();
+    } else if (threadIdx.x == 0) {
+        atomicAdd(&stats[stat_base], 1u);
+    }
+    uint32_t cnt = 0;
+    for (int p = 0; p < 3; p++) {  // workgroup-uniform loop: dx = -1, 0, +1 keeps the visit order
+        NbPlaneRuns R;
+        if (mode_a) {
+            R = (p == 0) ? R0 : (p == 1) ? R1 : R2;
+        } else {
+            // mode B: plane by plane.  List entries index the staging about to be replaced.
+            phase2(cnt);
+            cnt = 0;
+            const uint32_t cp = (p == 0) ? c0 : (p == 1) ? c1 : c2;
+            if (cp > NB_CAP) {
+                if (threadIdx.x == 0) atomicAdd(&stats[stat_base + 2], 1u);
+                direct(p, p + 1);
+                continue;
+            }
+            if (lds_busy) __syncthreads();  // everyone is done reading the previous plane's LDS
+            used = 0;
+            R = nb_stage_plane<WITH_RHO>(t, g, p, (p == 0) ? m0 : (p == 1) ? m1 : m2, used, start, i, valid, c, pred,
+                                         rho, self_l);
+            __syncthreads();
+            lds_busy = true;
+        }
+        // virtual index range of this plane
+        const uint32_t b0 = R.a & 0xFFFFu, n0 = (R.a >> 16) - b0;
+        const uint32_t b1 = R.b & 0xFFFFu, n01 = n0 + (R.b >> 16) - b1;
+        const uint32_t b2 = R.c & 0xFFFFu, T = n01 + (R.c >> 16) - b2;
+        const uint32_t o0 = b0, o1 = b1 - n0, o2 = b2 - n01;
+        const bool self_plane = SKIP_SELF && p == 1;
+        uint32_t v = 0;
+        for (;;) {
+            while (v < T && cnt < NB_K) {
+                const uint32_t v1 = v + 1;
+                const bool has1 = v1 < T;
+                const uint32_t a0 = v + ((v < n0) ? o0 : (v < n01) ? o1 : o2);
+                const uint32_t a1 = has1 ? v1 + ((v1 < n0) ? o0 : (v1 < n01) ? o1 : o2) : a0;
+                const float4 q0 = t.sm[a0];
+                const float4 q1 = t.sm[a1];
+                if (!WITH_RHO) asm volatile("" ::"v"(q0.w), "v"(q1.w));  // keep the 16-B LDS read (ds_read_b128)
+                const float ex0 = q0.x - o.x, ey0 = q0.y - o.y, ez0 = q0.z - o.z;
+                const float ex1 = q1.x - o.x, ey1 = q1.y - o.y, ez1 = q1.z - o.z;
+                const float d20 = ex0 * ex0 + ey0 * ey0 + ez0 * ez0;
+                const float d21 = ex1 * ex1 + ey1 * ey1 + ez1 * ez1;
+                if (!(d20 > d.d2_accept) && !(self_plane && a0 == self_l)) {
+                    t.list[cnt * NB_P + threadIdx.x] = (uint16_t)a0;
+                    cnt++;
+                }
+                if (has1 && !(d21 > d.d2_accept) && !(self_plane && a1 == self_l)) {
+                    t.list[cnt * NB_P + threadIdx.x] = (uint16_t)a1;
+                    cnt++;
+                }
+                v += 2;
+            }
+            if (!__ballot(cnt >= NB_K && v < T)) break;  // nobody is blocked on a full list
+            phase2(cnt);
+            cnt = 0;
+        }
+    }
+    phase2(cnt);
+}
+
+__global__ void __launch_bounds__(NB_P, 4) k_density_tiled(WsDev d, uint32_t ntiles, const uint32_t *__restrict__ start,
+                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                           float *__restrict__ rho, uint32_t *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t tile = nb_tile_index(ntiles);
+    if (tile >= ntiles) return;
+    const NbTile t = nb_carve(smem);
+    const uint32_t i0 = tile * NB_P, i = i0 + threadIdx.x;
+    const bool valid = i < d.n;
+    const uint32_t iv = valid ? i : d.n - 1u;
+    const int c = (int)cid_srt[iv];
+    const float4 o = srt.pred[iv];
+    float density = 0.f, near_density = 0.f;
+    nb_tile_run<false, false>(
+        d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, nullptr, stats, 0,
+        [&](uint32_t cnt) {
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float4 q = t.sm[t.list[k * NB_P + threadIdx.x]];
+                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+                density_pair(d, ex * ex + ey * ey + ez * ez, density, near_density, 1u);
+            }
+        },
+        [&](int p0, int p1) {
+            if (valid) density_direct<false>(d, start, c, o, srt.pred, nullptr, density, near_density, p0, p1);
+        });
+    if (valid) density_store(density, near_density, i, rho, srt.vel);
+}
+
+__global__ void __launch_bounds__(NB_P, 4) k_force_tiled(WsDev d, uint32_t ntiles, const uint32_t *__restrict__ start,
+                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                         const float *__restrict__ rho, WsSoA out,
+                                                         float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                                         uint32_t *__restrict__ count, uint32_t *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t tile = nb_tile_index(ntiles);
+    if (tile >= ntiles) return;
+    const NbTile t = nb_carve(smem);
+    const uint32_t i0 = tile * NB_P, i = i0 + threadIdx.x;
+    const bool valid = i < d.n;
+    const uint32_t iv = valid ? i : d.n - 1u;
+    const int c = (int)cid_srt[iv];
+    const float4 o = srt.pred[iv];
+    const float4 vel = srt.vel[iv];  // w = own near density
+    const float rho_x = rho[iv];
+    const float pressure = d.pressure_scalar * (rho_x - d.target_density);
+    const float near_pressure = d.near_pressure_scalar * vel.w;
+    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    nb_tile_run<true, true>(
+        d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, rho, stats, 1,
+        [&](uint32_t cnt) {
+            // the neighbour's velocity + near density is one 16-B gather by its global index,
+            // issued one list entry ahead of the arithmetic that consumes it
+            float4 nvel_next = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t idx_next = 0;
+            if (cnt > 0) {
+                idx_next = t.list[threadIdx.x];
+                nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
+            }
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t idx = idx_next;
+                const float4 nvel = nvel_next;
+                if (k + 1 < cnt) {
+                    idx_next = t.list[(k + 1) * NB_P + threadIdx.x];
+                    nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
+                }
+                const float4 q = t.sm[idx];
+                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+                force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure,
+                           acc, 1u);
+            }
+        },
+        [&](int p0, int p1) {
+            if (valid)
+                force_direct<false>(d, start, c, i, o, vel, pressure, near_pressure, srt.pred, srt.vel, rho, nullptr,
+                                    acc, p0, p1);
+        });
+    if (valid) force_store_integrate_bin(d, acc, rho_x, vel, i, srt.pos, out, accel, cid_out, count);
+}
+
+static bool g_tiled_attr_done = false;
+static void nb_set_attrs()
+{
+    if (g_tiled_attr_done) return;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_density_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        NB_LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_force_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        NB_LDS_BYTES);
+    g_tiled_attr_done = true;
+}
+
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, float *rho,
+                 const uint8_t *mult, bool alias, int variant, uint32_t *stats)
+{
+    if (alias) {
+        hipLaunchKernelGGL(k_density_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
+                           srt, rho, mult);
+    } else if (variant == WS_VARIANT_SIMPLE) {
+        hipLaunchKernelGGL(k_density_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
+                           srt, rho, mult);
+    } else {
+        nb_set_attrs();
+        const uint32_t ntiles = cdiv(d.n, NB_P);
+        hipLaunchKernelGGL(k_density_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
+                           cid_srt, srt, rho, stats);
+    }
+}
+
+void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+               const float *rho, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult,
+               bool alias, int variant, uint32_t *stats)
+{
+    if (alias) {
+        hipLaunchKernelGGL(k_force_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt, srt,
+                           rho, out, accel, cid_out, count, mult);
+    } else if (variant == WS_VARIANT_SIMPLE) {
+        hipLaunchKernelGGL(k_force_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
+                           srt, rho, out, accel, cid_out, count, mult);
+    } else {
+        nb_set_attrs();
+        const uint32_t ntiles = cdiv(d.n, NB_P);
+        hipLaunchKernelGGL(k_force_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
+                           cid_srt, srt, rho, out, accel, cid_out, count, stats);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -490,7 +884,8 @@ void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint
     hipLaunchKernelGGL(k_gather_positions, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, out_xyz, n);
 }
 
-__global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, const float2 *__restrict__ dens,
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, const float *__restrict__ rho,
+                                                               const float4 *__restrict__ srt_vel,
                                                                const float4 *__restrict__ accel, int have_step,
                                                                ws_particle80 *__restrict__ out, uint32_t n)
 {
@@ -500,11 +895,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
     const size_t id = __float_as_uint(p.w);
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_step) {
-        const float2 r = dens[i];
-        dp.x = r.x;
-        dp.y = r.y;
-        dp.z = d.pressure_scalar * (r.x - d.target_density);  // simulation.wgsl:192-193
-        dp.w = d.near_pressure_scalar * r.y;
+        dp.x = rho[i];
+        dp.y = srt_vel[i].w;  // near density rides in the sorted velocity's w lane
+        dp.z = d.pressure_scalar * (dp.x - d.target_density);  // simulation.wgsl:192-193
+        dp.w = d.near_pressure_scalar * dp.y;
         a = accel[i];
     }
     float4 *rec = reinterpret_cast<float4 *>(out + id);
@@ -515,10 +909,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
     rec[4] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
-void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float2 *dens, const float4 *accel,
-                          bool have_step, ws_particle80 *out, uint32_t n)
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float *rho, const float4 *srt_vel,
+                          const float4 *accel, bool have_step, ws_particle80 *out, uint32_t n)
 {
-    hipLaunchKernelGGL(k_gather_particles, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, dens, accel,
+    hipLaunchKernelGGL(k_gather_particles, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, rho, srt_vel, accel,
                        have_step ? 1 : 0, out, n);
 }
 

@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "ws_bit_sorter_stage_count", "ws_status_string", "ws_abi_version", "ws_create", "ws_destroy",
     "ws_step", "ws_ready", "ws_sync", "ws_set_params", "ws_read_positions", "ws_read_particles",
     "ws_reset", "ws_write_particles", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
-    "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_grid_dims",
+    "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
+    "ws_grid_dims", "ws_read_stats",
 ]
 
 
@@ -125,7 +126,9 @@ def load_library():
     L.ws_kernel_name.restype = C.c_char_p
     L.ws_profile_read.argtypes = [vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.ws_profile_reset.argtypes = [vp]
+    L.ws_profile_select.argtypes = [vp, u32]
     L.ws_grid_dims.argtypes = [vp, vp]
+    L.ws_read_stats.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -276,6 +279,12 @@ class FluidWorker:
         self._check(self._L.ws_grid_dims(self._h, d.ctypes.data))
         return tuple(int(x) for x in d)
 
+    def stats(self):
+        out = np.zeros(16, np.uint32)
+        self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
+        names = ["density_planewise_tiles", "force_planewise_tiles", "density_direct_planes", "force_direct_planes"]
+        return {k: int(out[i]) for i, k in enumerate(names)}
+
     def profile(self):
         """{kernel name: (total_ms, launches)} since the last profile_reset (needs profile=True)."""
         out = {}
@@ -285,6 +294,9 @@ class FluidWorker:
             self._check(self._L.ws_profile_read(self._h, k, C.byref(ms), C.byref(cnt)))
             out[name] = (ms.value, int(cnt.value))
         return out
+
+    def profile_select(self, mask):
+        self._check(self._L.ws_profile_select(self._h, mask & 0xFFFFFFFF))
 
     def profile_reset(self):
         self._check(self._L.ws_profile_reset(self._h))
