@@ -96,13 +96,14 @@ def _run_variant(ws, variant, pos, params, steps):
     return out
 
 
-@pytest.mark.parametrize("name,dist,steps", [("c2", "cloud", 12), ("c2", "lattice", 6), ("c1", "cloud", 8)])
+@pytest.mark.parametrize("name,dist,steps", [("c2", "cloud", 12), ("c2", "lattice", 6), ("c1", "cloud", 8), ("c2", "cloud", 150)])
 def test_tiled_kernels_equal_simple_kernels_bitwise(ws, name, dist, steps):
-    """The LDS-tiled density/force kernels visit neighbours in the same order with the same IEEE
+    """The LDS-tiled (+ listed for dense tiles) and the all-listed density/force kernels visit neighbours in the same order with the same IEEE
     operations as the one-thread-per-particle kernels: every field must be bit-identical, also
     after several free-running steps (any divergence would be amplified, not hidden)."""
     pos, params = ws.workloads.make_workload(name, dist)
     a = _run_variant(ws, "simple", pos, params, steps)
-    b = _run_variant(ws, "tiled", pos, params, steps)
-    for f in a.dtype.names:
-        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+    for variant in ("tiled", "listed"):
+        b = _run_variant(ws, variant, pos, params, steps)
+        for f in a.dtype.names:
+            assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), (variant, f)

@@ -290,8 +290,8 @@ void free_all(ws_handle *h)
     free_grid(h);
     hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
     hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
-    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->rho); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
+    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
+    hipFree(h->slot_tmp); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
     if (h->done) hipEventDestroy(h->done);
@@ -431,7 +431,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     h->flags = cfg ? cfg->flags : 0;
     h->n = n;
     h->params = *params;
-    if (const char *v = getenv("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : WS_VARIANT_TILED;
+    if (const char *v = getenv("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : strcmp(v, "tiled") == 0 ? WS_VARIANT_TILED : WS_VARIANT_LISTED;
 
     auto bail = [&](ws_status s) {
         g_create_error = h->err;
@@ -455,7 +455,8 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
     CREATE_TRY(derive_dev(h, *params, n, &h->dev));
-    const size_t n16 = (size_t)n * 16;
+    // +16 entries: phase 1 trips read up to U-1 slots past a run's end (masked, but must be mapped)
+    const size_t n16 = ((size_t)n + 16) * 16;
     CREATE_HIP(hipMalloc(&h->cur.pos, n16));
     CREATE_HIP(hipMalloc(&h->cur.vel, n16));
     CREATE_HIP(hipMalloc(&h->cur.pred, n16));
@@ -464,9 +465,10 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->srt.pred, n16));
     CREATE_HIP(hipMalloc(&h->cid_cur, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
-    CREATE_HIP(hipMalloc(&h->rho, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
+    CREATE_HIP(hipMalloc(&h->tile_list, (size_t)wsk_tile_list_words(n) * 4));
+    CREATE_HIP(hipMemset(h->tile_list, 0, 4));
     CREATE_HIP(hipMalloc(&h->stats, 64));
     CREATE_HIP(hipMemset(h->stats, 0, 64));
     CREATE_TRY(alloc_grid(h));
@@ -514,12 +516,12 @@ ws_status ws_step(ws_handle *h)
     }
     {
         Prof p(h, WS_K_DENSITY);
-        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->rho, h->mult, h->alias, h->variant, h->stats);
+        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->tile_list, h->stats);
     }
     {
         Prof p(h, WS_K_FORCE);
-        wsk_force(s, d, h->start, h->cid_srt, h->srt, h->rho, h->cur, h->accel, h->cid_cur, h->count, h->mult,
-                  h->alias, h->variant, h->stats);
+        wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
+                  h->variant, h->tile_list);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));
@@ -600,8 +602,7 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
-    wsk_gather_particles(h->stream, h->dev, h->cur, h->rho, h->srt.vel, h->accel, h->steps > 0,
-                         (ws_particle80 *)h->stage, h->n);
+    wsk_gather_particles(h->stream, h->dev, h->cur, h->srt, h->accel, h->steps > 0, (ws_particle80 *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

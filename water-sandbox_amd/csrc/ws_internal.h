@@ -30,13 +30,13 @@ struct WsDev {
 };
 
 // density / force kernel family (WS_VARIANT=simple|tiled in the environment, for A/B tests)
-enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_TILED = 1 };
+enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_TILED = 1, WS_VARIANT_LISTED = 2 };
 
 // SoA particle set (one of two ping-pong copies).
 struct WsSoA {
     float4 *pos;   // xyz = position, w = particle id (bits)
     float4 *vel;   // xyz = velocity (sorted copy: w = near density after K4)
-    float4 *pred;  // xyz = predicted_position
+    float4 *pred;  // xyz = predicted_position (sorted copy: w = density after K4)
 };
 
 struct WsEventPair {
@@ -61,8 +61,7 @@ struct ws_handle {
     WsSoA srt{};   // cell-sorted copy the density/force kernels read
     uint32_t *cid_cur = nullptr;  // cell id per particle of `cur`
     uint32_t *cid_srt = nullptr;  // cell id per particle of `srt`
-    float *rho = nullptr;         // density in `srt` order (near density rides in srt.vel[i].w)
-    int variant = WS_VARIANT_TILED;
+    int variant = WS_VARIANT_LISTED;  // density / near density ride in srt.pred[i].w / srt.vel[i].w
     float4 *accel = nullptr;      // acceleration in `srt` order
     uint32_t *slot_tmp = nullptr; // particle index per tentative slot
     uint32_t *count = nullptr;    // per-cell particle count (histogram)
@@ -70,6 +69,7 @@ struct ws_handle {
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
     uint32_t *bsum = nullptr;     // scan block sums
     uint32_t nscan_blocks = 0;
+    uint32_t *tile_list = nullptr; // [0] = tiles handed to the listed kernels this step, [1..] = their ids
     uint32_t *stats = nullptr;    // device counters: [0]/[1] density/force tiles that overflowed LDS
     uint8_t *mult = nullptr;      // 27 stencil multiplicities (hash aliasing), device
     bool alias = false;
@@ -102,14 +102,15 @@ uint32_t wsk_scan_blocks(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur,
                  const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, float *rho,
-                 const uint8_t *mult, bool alias, int variant, uint32_t *stats);
-void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-               const float *rho, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult,
-               bool alias, int variant, uint32_t *stats);
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats);
+uint32_t wsk_tile_list_words(uint32_t n);
+void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
+               float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant,
+               const uint32_t *tile_list);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
-void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float *rho, const float4 *srt_vel,
-                          const float4 *accel, bool have_step, ws_particle80 *out, uint32_t n);
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+                          ws_particle80 *out, uint32_t n);
 // reference-layout view
 void wsk_view_keys(hipStream_t s, const WsDev &d, const float4 *pred, const float4 *pos_with_id,
                    uint32_t *keys_by_id, uint32_t *count);

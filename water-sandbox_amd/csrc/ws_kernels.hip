@@ -10,6 +10,8 @@
 // each operation is one IEEE binary32 operation (hipcc's default f32 divide and sqrt
 // are correctly rounded).  What differs from the reference is only the ORDER in which
 // neighbours are visited (dense-grid order instead of hashed-bucket order).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "ws_internal.h"
@@ -308,11 +310,10 @@ __device__ __forceinline__ uint32_t alias_mult(const WsDev &d, const uint8_t *__
 }
 
 // ---------------------------------------------------------------------------------
-// per-pair arithmetic of K4 / K5, shared by the tiled and the simple kernels.
-// `o` = own predicted position, `q` = neighbour's; d2 has already passed the radius test.
+// per-pair arithmetic of K4 / K5, shared by every kernel variant.
 // ---------------------------------------------------------------------------------
 
-// simulation.wgsl:176-183
+// simulation.wgsl:176-183; d2 has already passed the radius test
 __device__ __forceinline__ void density_pair(const WsDev &d, float d2, float &density, float &near_density,
                                              uint32_t mult)
 {
@@ -328,8 +329,9 @@ struct ForceAcc {
     float pfx, pfy, pfz, vfx, vfy, vfz;
 };
 
-// simulation.wgsl:238-263.  nrho = (density, near density) of the neighbour; pressures are
-// recomputed from them (simulation.wgsl:192-193: the same two IEEE operations K4 stored).
+// simulation.wgsl:238-263.  (ex,ey,ez) = neighbour.pred - own.pred, d2 its squared length.
+// nrho_x / nrho_y = the neighbour's density / near density; its pressures are recomputed
+// from them (simulation.wgsl:192-193: the same two IEEE operations K4 would have stored).
 __device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, float ez, float d2, float nrho_x,
                                            float nrho_y, float4 nvel, float4 vel, float pressure, float near_pressure,
                                            ForceAcc &a, uint32_t mult)
@@ -362,15 +364,16 @@ __device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, f
     }
 }
 
-// K4 epilogue (simulation.wgsl:186-194): density goes to rho[i], near density rides in the
-// unused w lane of the sorted velocity (nobody reads velocities during K4).
-__device__ __forceinline__ void density_store(float density, float near_density, uint32_t i, float *__restrict__ rho,
-                                              float4 *__restrict__ vel)
+// K4 epilogue (simulation.wgsl:186-194).  Density and near density ride in the w lanes of the
+// particle's sorted predicted position and velocity, so K5 gets {pred.xyz, density} and
+// {vel.xyz, near density} of a neighbour in two 16-B loads.  Other workgroups are still
+// reading pred.xyz while this w is written: different floats, never the same memory location.
+__device__ __forceinline__ void density_store(float density, float near_density, uint32_t i, WsSoA srt)
 {
     density = density + 0.00001f;  // DENSITY_PADDING, simulation.wgsl:4,187-188
     near_density = near_density + 0.00001f;
-    rho[i] = density;
-    reinterpret_cast<float *>(vel + i)[3] = near_density;
+    reinterpret_cast<float *>(srt.pred + i)[3] = density;
+    reinterpret_cast<float *>(srt.vel + i)[3] = near_density;
 }
 
 // K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
@@ -408,23 +411,27 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
 }
 
 // ---------------------------------------------------------------------------------
-// direct candidate walks: one lane, candidates straight from global memory, for the dx
-// planes [P0, P1).  Used by the simple kernels (all three planes), when the reference's
-// hashed table would alias inside one stencil (tiny N: multiplicity table), and as the
-// per-plane fallback of a tile whose candidates do not fit in LDS.
+// variant "simple": one lane per particle, one candidate per loop trip, pair arithmetic
+// inline.  The reference-shaped baseline of the A/B tests, and the path used when the
+// reference's hashed table would alias inside one stencil (tiny N: multiplicity table).
 // ---------------------------------------------------------------------------------
 template <bool ALIAS>
-__device__ __forceinline__ void density_direct(const WsDev &d, const uint32_t *__restrict__ start, int c, float4 o,
-                                               const float4 *__restrict__ pred, const uint8_t *__restrict__ mult,
-                                               float &density, float &near_density, int p0 = 0, int p1 = 3)
+__global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint32_t *__restrict__ start,
+                                                             const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                             const uint8_t *__restrict__ mult)
 {
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.n) return;
+    const float4 o = srt.pred[i];
+    const int c = (int)cid_srt[i];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    for (int dx = p0 - 1; dx < p1 - 1; dx++) {
+    float density = 0.f, near_density = 0.f;
+    for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
             const uint32_t b = start[cc - 1], e = start[cc + 2];
             for (uint32_t j = b; j < e; j++) {
-                const float4 q = pred[j];
+                const float4 q = srt.pred[j];
                 const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
                 const float d2 = ex * ex + ey * ey + ez * ez;
                 if (d2 > d.d2_accept) continue;
@@ -432,98 +439,244 @@ __device__ __forceinline__ void density_direct(const WsDev &d, const uint32_t *_
             }
         }
     }
-}
-
-template <bool ALIAS>
-__device__ __forceinline__ void force_direct(const WsDev &d, const uint32_t *__restrict__ start, int c, uint32_t i,
-                                             float4 o, float4 vel, float pressure, float near_pressure,
-                                             const float4 *__restrict__ pred, const float4 *__restrict__ velarr,
-                                             const float *__restrict__ rho, const uint8_t *__restrict__ mult,
-                                             ForceAcc &acc, int p0 = 0, int p1 = 3)
-{
-    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    for (int dx = p0 - 1; dx < p1 - 1; dx++) {
-        for (int dy = -1; dy <= 1; dy++) {
-            const int cc = d.guard + c + dx * rowy + dy * rowz;
-            const uint32_t b = start[cc - 1], e = start[cc + 2];
-            for (uint32_t j = b; j < e; j++) {
-                if (j == i) continue;  // `particle_index == neighbour_index`, simulation.wgsl:232
-                const float4 q = pred[j];
-                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-                const float d2 = ex * ex + ey * ey + ez * ez;
-                if (d2 > d.d2_accept) continue;
-                const float4 nvel = velarr[j];
-                force_pair(d, ex, ey, ez, d2, rho[j], nvel.w, nvel, vel, pressure, near_pressure, acc,
-                           ALIAS ? alias_mult(d, mult, o, q) : 1u);
-            }
-        }
-    }
-}
-
-template <bool ALIAS>
-__global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint32_t *__restrict__ start,
-                                                             const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                             float *__restrict__ rho, const uint8_t *__restrict__ mult)
-{
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
-    float density = 0.f, near_density = 0.f;
-    density_direct<ALIAS>(d, start, (int)cid_srt[i], srt.pred[i], srt.pred, mult, density, near_density);
-    density_store(density, near_density, i, rho, srt.vel);
+    density_store(density, near_density, i, srt);
 }
 
 template <bool ALIAS>
 __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32_t *__restrict__ start,
-                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                           const float *__restrict__ rho, WsSoA out,
+                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
                                                            float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                            uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= d.n) return;
-    const float4 o = srt.pred[i];
-    const float4 vel = srt.vel[i];  // w = own near density
-    const float rho_x = rho[i];
-    const float pressure = d.pressure_scalar * (rho_x - d.target_density);
+    const float4 o = srt.pred[i];    // w = own density
+    const float4 vel = srt.vel[i];   // w = own near density
+    const float pressure = d.pressure_scalar * (o.w - d.target_density);
     const float near_pressure = d.near_pressure_scalar * vel.w;
+    const int c = (int)cid_srt[i];
+    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    force_direct<ALIAS>(d, start, (int)cid_srt[i], i, o, vel, pressure, near_pressure, srt.pred, srt.vel, rho, mult,
-                        acc);
-    force_store_integrate_bin(d, acc, rho_x, vel, i, srt.pos, out, accel, cid_out, count);
+    for (int dx = -1; dx <= 1; dx++) {
+        for (int dy = -1; dy <= 1; dy++) {
+            const int cc = d.guard + c + dx * rowy + dy * rowz;
+            const uint32_t b = start[cc - 1], e = start[cc + 2];
+            for (uint32_t j = b; j < e; j++) {
+                if (j == i) continue;  // `particle_index == neighbour_index`, simulation.wgsl:232
+                const float4 q = srt.pred[j];
+                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+                const float d2 = ex * ex + ey * ey + ez * ez;
+                if (d2 > d.d2_accept) continue;
+                const float4 nvel = srt.vel[j];
+                force_pair(d, ex, ey, ez, d2, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
+                           ALIAS ? alias_mult(d, mult, o, q) : 1u);
+            }
+        }
+    }
+    force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
 // ---------------------------------------------------------------------------------
-// tiled kernels: the MI355X form of K4 / K5.
+// Two-phase neighbour sweep, the core of the MI355X kernels.
 //
-// A workgroup owns NB_P consecutive particles of the cell-sorted order; their cells span
-// [c_lo, c_hi].  z is the fastest grid axis and y the next, so
-//   * for one (dx,dy) column offset the candidates of ALL of them are one contiguous particle
-//     range  [start[c_lo + s - 1], start[c_hi + s + 2]),  s = (dx*ny + dy)*nz   ("column" range);
-//   * for one dx plane the three column ranges lie inside one contiguous range
-//     [start[c_lo + dx*ny*nz - nz - 1], start[c_hi + dx*ny*nz + nz + 2])        ("merged" range),
-//     which is SMALLER than the three column ranges together when the tile spans several
-//     z-rows (sparse fluid) and larger when it sits inside one dense row.
-// Per plane the workgroup stages whichever is smaller (coalesced 16-B loads) into LDS, so every
-// candidate read of the hot loop is a ds_read_b128: all 3 planes at once if they fit (mode A),
-// else plane by plane (mode B); a plane that alone overflows LDS is walked from global memory.
-// Phase 1: each lane walks its runs (bounds in registers) doing ONLY the radius test and pushes
-// the LDS index of each accepted neighbour onto a per-lane list in LDS ([slot][lane] layout,
-// conflict-free).  Phase 2: the expensive pair arithmetic (sqrt, IEEE divides) runs over the
-// compacted list, i.e. on the ~15 % of candidates that pass.  When a list fills up the wave
-// flushes it through phase 2 and phase 1 resumes where it stopped, so any density works.
-// Every mode visits neighbours in (dx, dy, z, slot) order = the simple kernels' order, so all
-// paths give bit-identical sums.
+// The cell grid is z-fastest, so the 27 cells a particle searches are 9 contiguous particle
+// runs (one per (dx,dy) column, three z-cells each) instead of 27 hashed bucket walks.
+// Phase 1 walks each run with a plain counted loop -- U candidates per trip, their loads issued
+// together and differing only by an immediate offset -- doing ONLY the radius test; every
+// accepted candidate is pushed onto a per-lane list in LDS ([slot][lane] layout,
+// conflict-free; the store is unconditional, only the slot advance depends on the test).  Phase 2 then runs the expensive pair arithmetic (sqrt, the IEEE divides)
+// over the compacted list, i.e. on the ~15 % of candidates that pass, instead of dragging
+// it through every trip at ~15 % lane utilisation.  A list is flushed through phase 2 when
+// some lane of the wave is blocked on a full one, so any neighbour count works.
+// Visit order = (dx, dy, z, slot) ascending in every variant: all of them produce the same
+// sums bit for bit.
+//   fetch(a)            candidate a's {pred.xyz, density}
+//   push(slot, a, d2)   record an accepted candidate in list slot `slot`
+//   phase2(cnt)         consume the lane's list (cnt entries, in visit order)
 // ---------------------------------------------------------------------------------
-#define NB_P 512           // particles (= threads) per workgroup: 8 waves
+struct NbRange3 {
+    uint32_t b0, e0, b1, e1, b2, e2;  // the three runs [b, e) of the plane, in visit order
+};
+
+template <int K, int U, class Fetch, class Push, class Phase2>
+__device__ __forceinline__ void nb_run_phase1(const WsDev &d, float4 o, uint32_t j, uint32_t e, bool skip_self,
+                                              uint32_t self_a, uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2)
+{
+    // One contiguous run [j, e): candidate addresses are j, j+1, ... (the loads of a trip differ
+    // only by an immediate offset).  Lanes past their run's end keep loading in-bounds slots
+    // (every candidate array is padded by U entries) and are masked out of the accept test.
+    for (;;) {
+        while (j < e && cnt < (uint32_t)K) {
+            float4 q[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) q[u] = fetch(j + u);
+            __builtin_amdgcn_sched_barrier(0);  // all U loads are issued before any is consumed
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float ex = q[u].x - o.x, ey = q[u].y - o.y, ez = q[u].z - o.z;
+                const float d2 = ex * ex + ey * ey + ez * ez;
+                // branch-free push: always store at the current slot, advance it only on accept
+                const bool acc = (j + u < e) && !(d2 > d.d2_accept) && !(skip_self && j + u == self_a);
+                push(cnt, j + u, d2);
+                cnt += acc ? 1u : 0u;
+            }
+            j += U;
+        }
+        if (!__ballot(cnt >= (uint32_t)K && j < e)) break;  // nobody is blocked on a full list
+        phase2(cnt);
+        cnt = 0;
+    }
+}
+
+template <int K, int U, class Fetch, class Push, class Phase2>
+__device__ __forceinline__ void nb_plane_phase1(const WsDev &d, float4 o, NbRange3 r, bool skip_self, uint32_t self_a,
+                                                uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2)
+{
+    nb_run_phase1<K, U>(d, o, r.b0, r.e0, false, self_a, cnt, fetch, push, phase2);
+    nb_run_phase1<K, U>(d, o, r.b1, r.e1, skip_self, self_a, cnt, fetch, push, phase2);  // own cell is in the middle run
+    nb_run_phase1<K, U>(d, o, r.b2, r.e2, false, self_a, cnt, fetch, push, phase2);
+}
+
+// ---------------------------------------------------------------------------------
+// variant "listed" (default): one lane per particle, candidates straight from global memory.
+// Consecutive lanes are consecutive particles of the cell-sorted order, i.e. they sit in the
+// same or neighbouring cells: their candidate loads are the same or adjacent addresses, L1
+// serves them as broadcasts, and with no staging and no barriers the kernels run at full
+// occupancy.  (Measured against the LDS-staged variant below on C3: 10-25 % faster in the
+// sparse AND the dense regime -- DESIGN.md "Kernel variants".)  LDS holds only the per-lane
+// compacted lists.  If tile_list != nullptr only the NB_P-particle tiles it names are done.
+// ---------------------------------------------------------------------------------
+#define NB_P 512           // particles per tile of the "tiled" variant (and of tile lists)
+#define ND_P 256           // threads per workgroup
+#define ND_K 16            // list fill level that triggers a flush
+#define ND_ROWS(U) (ND_K + (U) - 1)
+
+__device__ __forceinline__ bool nd_particle(const WsDev &d, const uint32_t *__restrict__ tile_list, uint32_t &i)
+{
+    if (tile_list) {
+        const uint32_t entry = blockIdx.x / (NB_P / ND_P);
+        if (entry >= tile_list[0]) return false;
+        i = tile_list[1u + entry] * NB_P + (blockIdx.x % (NB_P / ND_P)) * ND_P + threadIdx.x;
+    } else {
+        i = blockIdx.x * ND_P + threadIdx.x;
+    }
+    return true;
+}
+
+template <int U, bool SKIP_SELF, class Push, class Phase2>
+__device__ __forceinline__ void nd_run(const WsDev &d, const uint32_t *__restrict__ start, int c, uint32_t i, bool valid,
+                                       float4 o, const float4 *__restrict__ pred, Push &&push, Phase2 &&phase2)
+{
+    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    uint32_t cnt = 0;
+    for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
+        const int cc = d.guard + c + (p - 1) * rowy;
+        NbRange3 r = {0, 0, 0, 0, 0, 0};
+        if (valid) {
+            r.b0 = start[cc - rowz - 1];
+            r.e0 = start[cc - rowz + 2];
+            r.b1 = start[cc - 1];
+            r.e1 = start[cc + 2];
+            r.b2 = start[cc + rowz - 1];
+            r.e2 = start[cc + rowz + 2];
+        }
+        nb_plane_phase1<ND_K, U>(
+            d, o, r, SKIP_SELF && p == 1, i, cnt, [&](uint32_t a) { return pred[a]; }, push, phase2);
+    }
+    phase2(cnt);
+}
+
+template <int U>
+__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ tile_list,
+                                                         const uint32_t *__restrict__ start,
+                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                         uint32_t *__restrict__ stats)
+{
+    __shared__ float list[ND_ROWS(U) * ND_P];  // K4's phase 2 needs only d2: the list holds it
+    if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], tile_list[0]);
+    uint32_t i;
+    if (!nd_particle(d, tile_list, i)) return;
+    const bool valid = i < d.n;
+    const uint32_t iv = valid ? i : d.n - 1u;
+    const float4 o = srt.pred[iv];
+    float density = 0.f, near_density = 0.f;
+    nd_run<U, false>(
+        d, start, (int)cid_srt[iv], i, valid, o, srt.pred,
+        [&](uint32_t slot, uint32_t, float d2) { list[slot * ND_P + threadIdx.x] = d2; },
+        [&](uint32_t cnt) {
+            for (uint32_t k = 0; k < cnt; k++)
+                density_pair(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
+        });
+    if (valid) density_store(density, near_density, i, srt);
+}
+
+template <int U>
+__global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *__restrict__ tile_list,
+                                                       const uint32_t *__restrict__ start,
+                                                       const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
+                                                       float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                                       uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t list[ND_ROWS(U) * ND_P];  // global indices of the accepted neighbours
+    uint32_t i;
+    if (!nd_particle(d, tile_list, i)) return;
+    const bool valid = i < d.n;
+    const uint32_t iv = valid ? i : d.n - 1u;
+    const float4 o = srt.pred[iv];   // w = own density
+    const float4 vel = srt.vel[iv];  // w = own near density
+    const float pressure = d.pressure_scalar * (o.w - d.target_density);
+    const float near_pressure = d.near_pressure_scalar * vel.w;
+    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    nd_run<U, true>(
+        d, start, (int)cid_srt[iv], i, valid, o, srt.pred,
+        [&](uint32_t slot, uint32_t a, float) { list[slot * ND_P + threadIdx.x] = a; },
+        [&](uint32_t cnt) {
+            // two 16-B gathers per accepted neighbour ({pred, density}, {vel, near density}),
+            // issued one list entry ahead of the arithmetic that consumes them
+            float4 q_next = o, nvel_next = vel;
+            if (cnt > 0) {
+                const uint32_t j = list[threadIdx.x];
+                q_next = srt.pred[j];
+                nvel_next = srt.vel[j];
+            }
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float4 q = q_next, nvel = nvel_next;
+                if (k + 1 < cnt) {
+                    const uint32_t j = list[(k + 1) * ND_P + threadIdx.x];
+                    q_next = srt.pred[j];
+                    nvel_next = srt.vel[j];
+                }
+                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+                force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure,
+                           acc, 1u);
+            }
+        });
+    if (valid) force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
+}
+
+// ---------------------------------------------------------------------------------
+// variant "tiled": the LDS-staged form, kept selectable (WS_VARIANT=tiled) for A/B runs.
+//
+// A workgroup owns NB_P consecutive particles of the sorted order; their cells span
+// [c_lo, c_hi].  For one (dx,dy) column offset the candidates of ALL of them are one
+// contiguous particle range [start[c_lo + s - 1], start[c_hi + s + 2]) ("column" range), and
+// for one dx plane the three column ranges lie inside one contiguous "merged" range
+// [start[c_lo + dx*ny*nz - nz - 1], start[c_hi + dx*ny*nz + nz + 2]), which is smaller than the
+// three together when the tile spans several z-rows (sparse fluid).  Per plane the workgroup
+// stages whichever is smaller into LDS (coalesced 16-B loads); phase 1 then reads candidates
+// with ds_read_b128.  Tiles whose three planes do not fit in LDS at once (dense rows) are
+// appended to a tile list and done by the listed kernels.
+// ---------------------------------------------------------------------------------
 #define NB_K 16            // neighbour-list fill level that triggers a flush
-#define NB_ROWS (NB_K + 1) // list rows: the 2-wide test may push one entry past NB_K
+#define NB_U 2
+#define NB_ROWS (NB_K + NB_U - 1)
 #define NB_CAP 3968        // staged candidates per workgroup (float4 each)
 #define NB_ALIGN 32        // each staged range starts on a multiple of this
 #define NB_TAB (NB_CAP / NB_ALIGN)
 #define NB_LDS_BYTES (NB_CAP * 16 + NB_ROWS * NB_P * 2 + NB_TAB * 4)  // 81 392 B: 2 workgroups / CU
 
 struct NbTile {
-    float4 *sm;       // [NB_CAP] staged {pred.xyz, w}
+    float4 *sm;       // [NB_CAP] staged {pred.xyz, density}
     uint16_t *list;   // [NB_ROWS][NB_P]
     int32_t *tab;     // [NB_TAB] (global index - LDS index) of the range covering each 32-slot group
 };
@@ -584,31 +737,17 @@ __device__ __forceinline__ uint32_t nb_plane_cost(const NbGeo &g, const uint32_t
     return merged ? cm : cs;
 }
 
-// a lane's three runs in one plane, each packed as (first LDS index) | (one past last) << 16
-struct NbPlaneRuns {
-    uint32_t a, b, c;
-};
-
-// Stage plane p (workgroup-uniform, may be a run-time value) at LDS slot `used` (advanced) and
-// return this lane's runs in it.  WITH_RHO fills the staged w lane with the candidate's density
-// and builds the LDS -> global index table (K5).  No barrier here.
-template <bool WITH_RHO>
-__device__ __forceinline__ NbPlaneRuns nb_stage_plane(const NbTile &t, const NbGeo &g, int p, bool merged,
-                                                      uint32_t &used, const uint32_t *__restrict__ start, uint32_t i,
-                                                      bool valid, int c, const float4 *__restrict__ pred,
-                                                      const float *__restrict__ rho, uint32_t &self_l)
+// Stage plane p at LDS slot `used` (advanced) and return this lane's three runs in it
+// (LDS indices).  No barrier here.
+__device__ __forceinline__ NbRange3 nb_stage_plane(const NbTile &t, const NbGeo &g, int p, bool merged, uint32_t &used,
+                                                   const uint32_t *__restrict__ start, uint32_t i, bool valid, int c,
+                                                   const float4 *__restrict__ pred, uint32_t &self_l)
 {
     uint32_t sg0[3], sl0[3];  // per column: first global particle / first LDS slot of its range
     auto stage_range = [&](uint32_t g0, uint32_t len, uint32_t l0) {
-        for (uint32_t k = threadIdx.x; k < len; k += NB_P) {
-            float4 q = pred[g0 + k];
-            if (WITH_RHO) q.w = rho[g0 + k];
-            t.sm[l0 + k] = q;
-        }
-        if (WITH_RHO) {
-            const uint32_t groups = nb_align(len) / NB_ALIGN;
-            if (threadIdx.x < groups) t.tab[l0 / NB_ALIGN + threadIdx.x] = (int32_t)(g0 - l0);
-        }
+        for (uint32_t k = threadIdx.x; k < len; k += NB_P) t.sm[l0 + k] = pred[g0 + k];
+        const uint32_t groups = nb_align(len) / NB_ALIGN;
+        if (threadIdx.x < groups) t.tab[l0 / NB_ALIGN + threadIdx.x] = (int32_t)(g0 - l0);
     };
     if (merged) {
         uint32_t g0, len;
@@ -627,34 +766,26 @@ __device__ __forceinline__ NbPlaneRuns nb_stage_plane(const NbTile &t, const NbG
             used += nb_align(len);
         }
     }
-    uint32_t r[3];
+    uint32_t b[3] = {0, 0, 0}, e[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int s = (p - 1) * g.rowy + (k - 1) * g.rowz;
-        uint32_t b = 0, e = 0;
         if (valid) {
-            b = start[g.guard + c + s - 1] - sg0[k] + sl0[k];
-            e = start[g.guard + c + s + 2] - sg0[k] + sl0[k];
+            b[k] = start[g.guard + c + s - 1] - sg0[k] + sl0[k];
+            e[k] = start[g.guard + c + s + 2] - sg0[k] + sl0[k];
         }
-        r[k] = b | (e << 16);
     }
     if (p == 1) self_l = i - sg0[1] + sl0[1];  // column (dx,dy) = (0,0) holds the lane's own cell
-    NbPlaneRuns R = {r[0], r[1], r[2]};
-    return R;
+    const NbRange3 r = {b[0], e[0], b[1], e[1], b[2], e[2]};
+    return r;
 }
 
-// The tile driver shared by K4 and K5.
-//   phase2(cnt)     consumes the lane's list (cnt entries, in visit order)
-//   direct(p0, p1)  walks planes [p0, p1) straight from global memory
-// Phase 1 sees a lane's three runs of one plane as ONE virtual index range [0, T): the LDS
-// address of virtual index v is v + o_k with k picked by two compares, so the hot loop is a
-// plain counted loop (two candidates per trip for ILP) with no run-hopping control flow.
-template <bool WITH_RHO, bool SKIP_SELF, class Phase2, class Direct>
-__device__ __forceinline__ void nb_tile_run(const WsDev &d, const NbTile &t, const uint32_t *__restrict__ start,
+// Returns false (workgroup-uniform, before touching LDS) when the tile's candidates do not fit
+// in LDS at once; such tiles go to the listed kernels.
+template <bool SKIP_SELF, class Phase2>
+__device__ __forceinline__ bool nb_tile_run(const WsDev &d, const NbTile &t, const uint32_t *__restrict__ start,
                                             const uint32_t *__restrict__ cid_srt, uint32_t i0, uint32_t i, bool valid,
-                                            int c, float4 o, const float4 *__restrict__ pred,
-                                            const float *__restrict__ rho, uint32_t *__restrict__ stats, int stat_base,
-                                            Phase2 &&phase2, Direct &&direct)
+                                            int c, float4 o, const float4 *__restrict__ pred, Phase2 &&phase2)
 {
     NbGeo g;
     g.c_lo = (int)cid_srt[i0];  // workgroup-uniform: scalar loads
@@ -665,81 +796,26 @@ __device__ __forceinline__ void nb_tile_run(const WsDev &d, const NbTile &t, con
     bool m0, m1, m2;
     const uint32_t c0 = nb_plane_cost(g, start, 0, m0), c1 = nb_plane_cost(g, start, 1, m1),
                    c2 = nb_plane_cost(g, start, 2, m2);
-    const bool mode_a = c0 + c1 + c2 <= NB_CAP;  // everything staged at once
-    NbPlaneRuns R0 = {0, 0, 0}, R1 = {0, 0, 0}, R2 = {0, 0, 0};
+    if (c0 + c1 + c2 > NB_CAP) return false;
     uint32_t self_l = 0, used = 0;
-    bool lds_busy = false;
-    if (mode_a) {
-        R0 = nb_stage_plane<WITH_RHO>(t, g, 0, m0, used, start, i, valid, c, pred, rho, self_l);
-        R1 = nb_stage_plane<WITH_RHO>(t, g, 1, m1, used, start, i, valid, c, pred, rho, self_l);
-        R2 = nb_stage_plane<WITH_RHO>(t, g, 2, m2, used, start, i, valid, c, pred, rho, self_l);
-        __syncthreads();
-    } else if (threadIdx.x == 0) {
-        atomicAdd(&stats[stat_base], 1u);
-    }
+    const NbRange3 R0 = nb_stage_plane(t, g, 0, m0, used, start, i, valid, c, pred, self_l);
+    const NbRange3 R1 = nb_stage_plane(t, g, 1, m1, used, start, i, valid, c, pred, self_l);
+    const NbRange3 R2 = nb_stage_plane(t, g, 2, m2, used, start, i, valid, c, pred, self_l);
+    __syncthreads();
     uint32_t cnt = 0;
     for (int p = 0; p < 3; p++) {  // workgroup-uniform loop: dx = -1, 0, +1 keeps the visit order
-        NbPlaneRuns R;
-        if (mode_a) {
-            R = (p == 0) ? R0 : (p == 1) ? R1 : R2;
-        } else {
-            // mode B: plane by plane.  List entries index the staging about to be replaced.
-            phase2(cnt);
-            cnt = 0;
-            const uint32_t cp = (p == 0) ? c0 : (p == 1) ? c1 : c2;
-            if (cp > NB_CAP) {
-                if (threadIdx.x == 0) atomicAdd(&stats[stat_base + 2], 1u);
-                direct(p, p + 1);
-                continue;
-            }
-            if (lds_busy) __syncthreads();  // everyone is done reading the previous plane's LDS
-            used = 0;
-            R = nb_stage_plane<WITH_RHO>(t, g, p, (p == 0) ? m0 : (p == 1) ? m1 : m2, used, start, i, valid, c, pred,
-                                         rho, self_l);
-            __syncthreads();
-            lds_busy = true;
-        }
-        // virtual index range of this plane
-        const uint32_t b0 = R.a & 0xFFFFu, n0 = (R.a >> 16) - b0;
-        const uint32_t b1 = R.b & 0xFFFFu, n01 = n0 + (R.b >> 16) - b1;
-        const uint32_t b2 = R.c & 0xFFFFu, T = n01 + (R.c >> 16) - b2;
-        const uint32_t o0 = b0, o1 = b1 - n0, o2 = b2 - n01;
-        const bool self_plane = SKIP_SELF && p == 1;
-        uint32_t v = 0;
-        for (;;) {
-            while (v < T && cnt < NB_K) {
-                const uint32_t v1 = v + 1;
-                const bool has1 = v1 < T;
-                const uint32_t a0 = v + ((v < n0) ? o0 : (v < n01) ? o1 : o2);
-                const uint32_t a1 = has1 ? v1 + ((v1 < n0) ? o0 : (v1 < n01) ? o1 : o2) : a0;
-                const float4 q0 = t.sm[a0];
-                const float4 q1 = t.sm[a1];
-                if (!WITH_RHO) asm volatile("" ::"v"(q0.w), "v"(q1.w));  // keep the 16-B LDS read (ds_read_b128)
-                const float ex0 = q0.x - o.x, ey0 = q0.y - o.y, ez0 = q0.z - o.z;
-                const float ex1 = q1.x - o.x, ey1 = q1.y - o.y, ez1 = q1.z - o.z;
-                const float d20 = ex0 * ex0 + ey0 * ey0 + ez0 * ez0;
-                const float d21 = ex1 * ex1 + ey1 * ey1 + ez1 * ez1;
-                if (!(d20 > d.d2_accept) && !(self_plane && a0 == self_l)) {
-                    t.list[cnt * NB_P + threadIdx.x] = (uint16_t)a0;
-                    cnt++;
-                }
-                if (has1 && !(d21 > d.d2_accept) && !(self_plane && a1 == self_l)) {
-                    t.list[cnt * NB_P + threadIdx.x] = (uint16_t)a1;
-                    cnt++;
-                }
-                v += 2;
-            }
-            if (!__ballot(cnt >= NB_K && v < T)) break;  // nobody is blocked on a full list
-            phase2(cnt);
-            cnt = 0;
-        }
+        const NbRange3 r = (p == 0) ? R0 : (p == 1) ? R1 : R2;
+        nb_plane_phase1<NB_K, NB_U>(
+            d, o, r, SKIP_SELF && p == 1, self_l, cnt, [&](uint32_t a) { return t.sm[a]; },
+            [&](uint32_t slot, uint32_t a, float) { t.list[slot * NB_P + threadIdx.x] = (uint16_t)a; }, phase2);
     }
     phase2(cnt);
+    return true;
 }
 
 __global__ void __launch_bounds__(NB_P, 4) k_density_tiled(WsDev d, uint32_t ntiles, const uint32_t *__restrict__ start,
                                                            const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                           float *__restrict__ rho, uint32_t *__restrict__ stats)
+                                                           uint32_t *__restrict__ tile_list)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t tile = nb_tile_index(ntiles);
@@ -751,26 +827,25 @@ __global__ void __launch_bounds__(NB_P, 4) k_density_tiled(WsDev d, uint32_t nti
     const int c = (int)cid_srt[iv];
     const float4 o = srt.pred[iv];
     float density = 0.f, near_density = 0.f;
-    nb_tile_run<false, false>(
-        d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, nullptr, stats, 0,
-        [&](uint32_t cnt) {
-            for (uint32_t k = 0; k < cnt; k++) {
-                const float4 q = t.sm[t.list[k * NB_P + threadIdx.x]];
-                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-                density_pair(d, ex * ex + ey * ey + ez * ez, density, near_density, 1u);
-            }
-        },
-        [&](int p0, int p1) {
-            if (valid) density_direct<false>(d, start, c, o, srt.pred, nullptr, density, near_density, p0, p1);
-        });
-    if (valid) density_store(density, near_density, i, rho, srt.vel);
+    const bool done = nb_tile_run<false>(d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, [&](uint32_t cnt) {
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float4 q = t.sm[t.list[k * NB_P + threadIdx.x]];
+            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+            density_pair(d, ex * ex + ey * ey + ez * ez, density, near_density, 1u);
+        }
+    });
+    if (!done) {
+        // dense tile: hand it to the listed kernels (this step's K4 and K5); tile_list[0] = count
+        if (threadIdx.x == 0) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile;
+        return;
+    }
+    if (valid) density_store(density, near_density, i, srt);
 }
 
 __global__ void __launch_bounds__(NB_P, 4) k_force_tiled(WsDev d, uint32_t ntiles, const uint32_t *__restrict__ start,
-                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                         const float *__restrict__ rho, WsSoA out,
+                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
                                                          float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                         uint32_t *__restrict__ count, uint32_t *__restrict__ stats)
+                                                         uint32_t *__restrict__ count)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t tile = nb_tile_index(ntiles);
@@ -780,42 +855,35 @@ __global__ void __launch_bounds__(NB_P, 4) k_force_tiled(WsDev d, uint32_t ntile
     const bool valid = i < d.n;
     const uint32_t iv = valid ? i : d.n - 1u;
     const int c = (int)cid_srt[iv];
-    const float4 o = srt.pred[iv];
+    const float4 o = srt.pred[iv];   // w = own density
     const float4 vel = srt.vel[iv];  // w = own near density
-    const float rho_x = rho[iv];
-    const float pressure = d.pressure_scalar * (rho_x - d.target_density);
+    const float pressure = d.pressure_scalar * (o.w - d.target_density);
     const float near_pressure = d.near_pressure_scalar * vel.w;
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    nb_tile_run<true, true>(
-        d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, rho, stats, 1,
-        [&](uint32_t cnt) {
-            // the neighbour's velocity + near density is one 16-B gather by its global index,
-            // issued one list entry ahead of the arithmetic that consumes it
-            float4 nvel_next = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t idx_next = 0;
-            if (cnt > 0) {
-                idx_next = t.list[threadIdx.x];
+    const bool done = nb_tile_run<true>(d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, [&](uint32_t cnt) {
+        // the neighbour's velocity + near density is one 16-B gather by its global index,
+        // issued one list entry ahead of the arithmetic that consumes it
+        float4 nvel_next = vel;
+        uint32_t idx_next = 0;
+        if (cnt > 0) {
+            idx_next = t.list[threadIdx.x];
+            nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
+        }
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t idx = idx_next;
+            const float4 nvel = nvel_next;
+            if (k + 1 < cnt) {
+                idx_next = t.list[(k + 1) * NB_P + threadIdx.x];
                 nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
             }
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t idx = idx_next;
-                const float4 nvel = nvel_next;
-                if (k + 1 < cnt) {
-                    idx_next = t.list[(k + 1) * NB_P + threadIdx.x];
-                    nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
-                }
-                const float4 q = t.sm[idx];
-                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-                force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure,
-                           acc, 1u);
-            }
-        },
-        [&](int p0, int p1) {
-            if (valid)
-                force_direct<false>(d, start, c, i, o, vel, pressure, near_pressure, srt.pred, srt.vel, rho, nullptr,
-                                    acc, p0, p1);
-        });
-    if (valid) force_store_integrate_bin(d, acc, rho_x, vel, i, srt.pos, out, accel, cid_out, count);
+            const float4 q = t.sm[idx];
+            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+            force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
+                       1u);
+        }
+    });
+    if (!done) return;  // in this step's tile list: k_force_listed does it
+    if (valid) force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
 static bool g_tiled_attr_done = false;
@@ -829,38 +897,84 @@ static void nb_set_attrs()
     g_tiled_attr_done = true;
 }
 
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, float *rho,
-                 const uint8_t *mult, bool alias, int variant, uint32_t *stats)
+uint32_t wsk_tile_list_words(uint32_t n) { return 1u + cdiv(n, NB_P); }
+
+// candidates per phase-1 trip of the listed kernels (WS_UNROLL=2|4|8 in the environment)
+static int nd_unroll()
 {
-    if (alias) {
-        hipLaunchKernelGGL(k_density_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
-                           srt, rho, mult);
-    } else if (variant == WS_VARIANT_SIMPLE) {
-        hipLaunchKernelGGL(k_density_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
-                           srt, rho, mult);
-    } else {
-        nb_set_attrs();
-        const uint32_t ntiles = cdiv(d.n, NB_P);
-        hipLaunchKernelGGL(k_density_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
-                           cid_srt, srt, rho, stats);
+    static int u = 0;
+    if (!u) {
+        const char *e = getenv("WS_UNROLL");
+        u = e ? atoi(e) : 4;
+        if (u != 2 && u != 4 && u != 8) u = 4;
+    }
+    return u;
+}
+
+static void launch_density_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
+                                  const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, uint32_t *stats)
+{
+    switch (nd_unroll()) {
+        case 2: hipLaunchKernelGGL(k_density_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, stats); break;
+        case 8: hipLaunchKernelGGL(k_density_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, stats); break;
+        default: hipLaunchKernelGGL(k_density_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, stats); break;
     }
 }
 
-void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-               const float *rho, WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult,
-               bool alias, int variant, uint32_t *stats)
+static void launch_force_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
+                                const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out, float4 *accel,
+                                uint32_t *cid_out, uint32_t *count)
 {
-    if (alias) {
-        hipLaunchKernelGGL(k_force_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt, srt,
-                           rho, out, accel, cid_out, count, mult);
-    } else if (variant == WS_VARIANT_SIMPLE) {
-        hipLaunchKernelGGL(k_force_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
-                           srt, rho, out, accel, cid_out, count, mult);
+    switch (nd_unroll()) {
+        case 2: hipLaunchKernelGGL(k_force_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count); break;
+        case 8: hipLaunchKernelGGL(k_force_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count); break;
+        default: hipLaunchKernelGGL(k_force_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count); break;
+    }
+}
+
+// tile_list (variant "tiled" only): [0] = number of tiles handed to the listed kernels this
+// step (zeroed here), [1..] = their indices
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats)
+{
+    if (alias || variant == WS_VARIANT_SIMPLE) {
+        if (alias)
+            hipLaunchKernelGGL(k_density_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                               cid_srt, srt, mult);
+        else
+            hipLaunchKernelGGL(k_density_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                               cid_srt, srt, mult);
+    } else if (variant == WS_VARIANT_TILED) {
+        nb_set_attrs();
+        const uint32_t ntiles = cdiv(d.n, NB_P);
+        hipMemsetAsync(tile_list, 0, 4, s);
+        hipLaunchKernelGGL(k_density_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
+                           cid_srt, srt, tile_list);
+        launch_density_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, stats);
     } else {
+        launch_density_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, stats);
+    }
+}
+
+void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
+               float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant,
+               const uint32_t *tile_list)
+{
+    if (alias || variant == WS_VARIANT_SIMPLE) {
+        if (alias)
+            hipLaunchKernelGGL(k_force_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
+                               srt, out, accel, cid_out, count, mult);
+        else
+            hipLaunchKernelGGL(k_force_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                               cid_srt, srt, out, accel, cid_out, count, mult);
+    } else if (variant == WS_VARIANT_TILED) {
         nb_set_attrs();
         const uint32_t ntiles = cdiv(d.n, NB_P);
         hipLaunchKernelGGL(k_force_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
-                           cid_srt, srt, rho, out, accel, cid_out, count, stats);
+                           cid_srt, srt, out, accel, cid_out, count);
+        launch_force_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, out, accel, cid_out, count);
+    } else {
+        launch_force_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, out, accel, cid_out, count);
     }
 }
 
@@ -884,8 +998,7 @@ void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint
     hipLaunchKernelGGL(k_gather_positions, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, out_xyz, n);
 }
 
-__global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, const float *__restrict__ rho,
-                                                               const float4 *__restrict__ srt_vel,
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, WsSoA srt,
                                                                const float4 *__restrict__ accel, int have_step,
                                                                ws_particle80 *__restrict__ out, uint32_t n)
 {
@@ -895,8 +1008,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
     const size_t id = __float_as_uint(p.w);
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_step) {
-        dp.x = rho[i];
-        dp.y = srt_vel[i].w;  // near density rides in the sorted velocity's w lane
+        dp.x = srt.pred[i].w;  // density / near density ride in the sorted copy's w lanes
+        dp.y = srt.vel[i].w;
         dp.z = d.pressure_scalar * (dp.x - d.target_density);  // simulation.wgsl:192-193
         dp.w = d.near_pressure_scalar * dp.y;
         a = accel[i];
@@ -909,10 +1022,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
     rec[4] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
-void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, const float *rho, const float4 *srt_vel,
-                          const float4 *accel, bool have_step, ws_particle80 *out, uint32_t n)
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+                          ws_particle80 *out, uint32_t n)
 {
-    hipLaunchKernelGGL(k_gather_particles, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, rho, srt_vel, accel,
+    hipLaunchKernelGGL(k_gather_particles, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, srt, accel,
                        have_step ? 1 : 0, out, n);
 }
 

@@ -282,7 +282,7 @@ class FluidWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        names = ["density_planewise_tiles", "force_planewise_tiles", "density_direct_planes", "force_direct_planes"]
+        names = ["listed_tiles"]
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def profile(self):
