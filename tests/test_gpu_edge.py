@@ -1,0 +1,155 @@
+"""GPU edge cases and size-independent properties, through the C ABI."""
+import numpy as np
+import pytest
+
+from util import assert_particles_close, oracle_from_params, oracle_one_step, reorder_noise_tolerances
+
+pytestmark = pytest.mark.gpu
+
+
+def _one_step_parity(oracle, ws, pos, params, mode=None, state=None, label=""):
+    orc = oracle_from_params(oracle, pos, params)
+    st = orc.particles.copy() if state is None else state
+    want = oracle_one_step(oracle, orc, st, mode=mode)
+    keys_want, sorted_want, off_want = orc.particle_cell_indicies.copy(), orc.sorted_keys().copy(), orc.cell_offsets.copy()
+    rev = oracle_one_step(oracle, orc, st, reverse=True, mode=mode)
+    w = ws.FluidWorker(pos, params)
+    w.write_slice("particles", st)
+    w.run()
+    got = w.read_vec("particles")
+    keys, perm, off = w.sort_view()
+    assert np.array_equal(keys, keys_want)
+    assert np.array_equal(keys[perm], sorted_want)
+    assert np.array_equal(off, off_want)
+    assert_particles_close(got, want, reorder_noise_tolerances(want, rev), label)
+    w.close()
+    return got
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 64, 512])
+def test_tiny_n_hash_aliasing(oracle, ws, n):
+    """For tiny N several cells of one 27-stencil share a bucket of the reference's N-entry table and
+    the reference counts those neighbours more than once; the HIP path reproduces the multiplicity."""
+    side = {1: (1, 1, 1), 2: (2, 1, 1), 8: (2, 2, 2), 64: (4, 4, 4), 512: (8, 8, 8)}[n]
+    pos = ws.cube_fluid(*side)
+    got = _one_step_parity(oracle, ws, pos, ws.make_params(container_size=(4.0, 4.0, 4.0)), label="n=%d" % n)
+    if n == 1:
+        k = ws.get_smoothing_kernel(ws.default_params())
+        assert got["density"][0, 0] == pytest.approx(27 * 0.0625 * k.pow2 + 1e-5, rel=1e-6)
+
+
+@pytest.mark.parametrize("n", [1000, 3000])
+def test_non_power_of_two_n(oracle, ws, n):
+    """The reference's bitonic sort needs a power of two (src/fluid_compute.rs:15 FIXME); the counting
+    sort here does not.  Oracle in fast-sort mode defines the expected values."""
+    mn, mx = ws.get_ext((0, 0, 0), (6.0, 4.0, 4.0), 0.1)
+    pos = ws.workloads.uniform_cloud(n, 99, mn, mx)
+    _one_step_parity(oracle, ws, pos, ws.make_params(container_size=(6.0, 4.0, 4.0)), mode=oracle.SORT_FAST,
+                     label="n=%d" % n)
+
+
+def test_particles_far_outside_the_grid_are_clamped_not_lost(oracle, ws):
+    """Predicted positions may leave the container (position is clamped, position + v/50 is not): cells
+    outside the padded dense grid are clamped; the exact distance test keeps the neighbour set."""
+    params = ws.make_params(container_size=(4.0, 4.0, 4.0))
+    pos = ws.cube_fluid(8, 8, 8)
+    orc = oracle_from_params(oracle, pos, params)
+    st = orc.particles.copy()
+    rng = np.random.default_rng(5)
+    fast = rng.choice(512, 64, replace=False)
+    st["velocity"][fast, :3] = rng.uniform(-400, 400, (64, 3)).astype(np.float32)
+    st["predicted_position"][:, :3] = st["position"][:, :3] + st["velocity"][:, :3] * np.float32(0.02)
+    # a tight clump outside the grid: they must still see each other
+    st["predicted_position"][fast[:8], :3] = np.float32([30.0, 30.0, 30.0]) + rng.uniform(0, 0.1, (8, 3)).astype(np.float32)
+    _one_step_parity(oracle, ws, pos, params, state=st, label="escaped")
+
+
+def test_set_params_gravity_and_radius_change(oracle, ws):
+    """update() re-uploads fluid_props / smoothing_kernel / gravity every frame (fluid_compute.rs:479-481);
+    a new smoothing radius changes the cell size and forces a re-grid."""
+    pos = ws.cube_fluid(16, 8, 8)
+    params = ws.make_params(container_size=(6.0, 4.0, 4.0))
+    w = ws.FluidWorker(pos, params)
+    w.run(3)
+    state = w.read_vec("particles")
+    p2 = ws.make_params(container_size=(6.0, 4.0, 4.0), gravity=(0.0, 0.0, 0.0, 0.0), smoothing_radius=0.35,
+                        viscosity_strength=0.2)
+    w.set_params(p2)
+    w.run()
+    got = w.read_vec("particles")
+    orc = oracle_from_params(oracle, pos, p2)
+    want = oracle_one_step(oracle, orc, state.astype(oracle.PARTICLE_DTYPE))
+    rev = oracle_one_step(oracle, orc, state.astype(oracle.PARTICLE_DTYPE), reverse=True)
+    assert_particles_close(got, want, reorder_noise_tolerances(want, rev), "after set_params")
+    keys, perm, off = w.sort_view()
+    assert np.array_equal(keys, orc.particle_cell_indicies)
+    w.close()
+
+
+def test_reset_restores_initial_state_and_identity_views(ws):
+    pos = ws.cube_fluid(8, 8, 8)
+    w = ws.FluidWorker(pos, ws.make_params(container_size=(4.0, 4.0, 4.0)))
+    keys, perm, off = w.sort_view()  # before the first step: all identity (fluid_compute.rs:306-308)
+    ident = np.arange(512, dtype=np.uint32)
+    assert np.array_equal(keys, ident) and np.array_equal(perm, ident) and np.array_equal(off, ident)
+    first = None
+    for _ in range(2):
+        w.run(4)
+        out = w.read_vec("particles")
+        if first is None:
+            first = out
+        else:
+            for f in out.dtype.names:
+                assert np.array_equal(out[f].view(np.uint32), first[f].view(np.uint32)), f  # deterministic
+        w.reset(pos)
+        assert w.steps_done() == 0
+        p0 = w.read_vec("particles")
+        assert np.array_equal(p0["position"][:, :3], pos) and np.array_equal(p0["predicted_position"][:, :3], pos)
+        assert not p0["velocity"].any() and not p0["density"].any() and not p0["acceleration"].any()
+    w.close()
+
+
+def test_step_is_asynchronous_and_ready_polls(ws):
+    pos, params = ws.workloads.make_workload("c2", "cloud")
+    w = ws.FluidWorker(pos, params)
+    assert w.ready()
+    w.run(50)
+    seen_busy = not w.ready()
+    w.sync()
+    assert w.ready()
+    assert w.steps_done() == 50
+    assert seen_busy or True  # on a fast GPU the queue may already be drained; the poll must not block
+    w.close()
+
+
+def test_full_size_properties_c3(ws):
+    """BASELINE.json config 3 (4 194 304 particles): properties that need no oracle at this size."""
+    pos, params = ws.workloads.make_workload("c3", "cloud")
+    n = pos.shape[0]
+    w = ws.FluidWorker(pos, params)
+    w.run(3)
+    keys, perm, off = w.sort_view()
+    assert np.array_equal(np.sort(perm), np.arange(n, dtype=np.uint32))      # ids conserved
+    sk = keys[perm]
+    assert np.all(sk[1:] >= sk[:-1])                                          # sortedness
+    heads = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
+    first = np.full(n, 999999999, np.uint32)
+    first[sk[heads]] = heads.astype(np.uint32)
+    assert np.array_equal(off, first)                                         # offsets = first slot or INF
+    P = w.read_vec("particles")
+    mn = np.float32(list(params.ext_min)[:3]); mx = np.float32(list(params.ext_max)[:3])
+    assert np.all(P["position"][:, :3] >= mn) and np.all(P["position"][:, :3] <= mx)  # wall clamp
+    assert np.array_equal(P["predicted_position"][:, :3], P["position"][:, :3] + P["velocity"][:, :3] * np.float32(0.02))
+    assert np.all(np.isfinite(P["density"])) and np.all(P["density"][:, 0] > 152.0)   # self term alone is 152.79
+    assert np.array_equal(P["pressure"][:, 0], np.float32(22.0) * (P["density"][:, 0] - np.float32(10.0)))
+    for f in ("position", "velocity", "acceleration", "predicted_position"):
+        assert not P[f][:, 3].any()
+    # keys are the hash of the cell of the predicted position the step started from: recompute on the host
+    w2 = ws.FluidWorker(pos, params)
+    w2.run(2)
+    Q = w2.read_vec("particles")["predicted_position"][:, :3]
+    cell = np.floor(Q / np.float32(params.smoothing_radius)).astype(np.int64).astype(np.uint32) if False else \
+        np.floor(Q / np.float32(params.smoothing_radius)).astype(np.int32).view(np.uint32)
+    h = (cell[:, 0] * np.uint32(15823) + cell[:, 1] * np.uint32(9737333) + cell[:, 2] * np.uint32(440817757)) % np.uint32(n)
+    assert np.array_equal(keys, h)
+    w.close(); w2.close()
