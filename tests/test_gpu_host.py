@@ -1,0 +1,23 @@
+"""The compiled C++ host mirror (water-sandbox_amd/host) driving the library in the reference's frame order."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_frame_loop_runs_reset_and_param_change():
+    exe = os.path.join(ROOT, "water-sandbox_amd", "host", "frame_loop")
+    if not os.path.exists(exe):
+        import runpy
+
+        runpy.run_path(os.path.join(ROOT, "water-sandbox_amd", "host", "build_host.py"), run_name="__main__")
+    out = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "60 frames, 65536 particles" in out.stdout
+    lines = [l for l in out.stdout.splitlines() if l.startswith("frame")]
+    ys = [float(l.split("=")[1]) for l in lines]
+    assert ys[1] < ys[0]          # falling under gravity
+    assert ys[3] > ys[2]          # frame 30 reset put the particle back up
