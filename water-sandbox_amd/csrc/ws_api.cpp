@@ -125,6 +125,9 @@ ws_status derive_dev(ws_handle *h, const ws_params &p, uint32_t n, WsDev *out)
     d.ncells = (uint32_t)cells;
     d.guard = d.dim[1] * d.dim[2] + d.dim[2] + 1;
     d.n = n;
+    d.base = 0;
+    d.gdim_x = d.dim[0];
+    d.xoff = 0;
     d.hash_n = n;
     h->sk = sk;
     *out = d;
@@ -291,7 +294,7 @@ void free_all(ws_handle *h)
     hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
     hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
+    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
     if (h->done) hipEventDestroy(h->done);
@@ -467,6 +470,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
+    CREATE_HIP(hipMalloc(&h->id_tmp, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->tile_list, (size_t)wsk_tile_list_words(n) * 4));
     CREATE_HIP(hipMemset(h->tile_list, 0, 4));
     CREATE_HIP(hipMalloc(&h->stats, 64));
@@ -504,15 +508,15 @@ ws_status ws_step(ws_handle *h)
     hipStream_t s = h->stream;
     {
         Prof p(h, WS_K_SCAN);
-        wsk_scan(s, h->count, h->start + d.guard, h->cursor, h->bsum, d.ncells, h->nscan_blocks, true);
+        wsk_scan(s, h->count, h->start + d.guard, h->cursor, h->bsum, d.ncells, h->nscan_blocks, true, 0);
     }
     {
         Prof p(h, WS_K_SCATTER);
-        wsk_scatter(s, h->cid_cur, h->cursor, h->slot_tmp, d.n);
+        wsk_scatter(s, h->cid_cur, h->cur.pos, h->cursor, h->slot_tmp, h->id_tmp, d.n);
     }
     {
         Prof p(h, WS_K_REORDER);
-        wsk_reorder(s, d, h->slot_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt);
+        wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt);
     }
     {
         Prof p(h, WS_K_DENSITY);
@@ -666,9 +670,8 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     HIP_TRY(h, hipMemsetAsync(h->v_count, 0, (size_t)n * 4, s));
     // the predicted positions the last step started from live in the sorted copy
     wsk_view_keys(s, h->dev, h->srt.pred, h->srt.pos, h->v_keys, h->v_count);
-    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, n, wsk_scan_blocks(n), false);
-    wsk_iota(s, h->v_perm, n);  // scratch: ids in id order as the scatter's input index
-    wsk_scatter(s, h->v_keys, h->v_cursor, h->v_tmp, n);
+    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, n, wsk_scan_blocks(n), false, 0);
+    wsk_scatter(s, h->v_keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n);
     wsk_view_fix(s, h->v_tmp, h->v_keys, h->v_start, h->v_perm, n);
     wsk_view_offsets(s, h->v_start, h->v_off, n);
     HIP_TRY(h, hipGetLastError());

@@ -24,7 +24,10 @@ struct WsDev {
     int32_t org[3];  // grid origin in cell coordinates
     int32_t dim[3];  // cells along x, y, z (z fastest in memory, x slowest)
     int32_t guard;   // guard entries in front of / behind cell_start
-    uint32_t n;      // particles
+    uint32_t n;      // particles the kernels process: sorted indices [base, base + n)
+    uint32_t base;   // first owned slot of the sorted arrays (0 on one GPU; ghosts sit in front of it in a slab)
+    int32_t gdim_x;  // cells along x of the GLOBAL grid (== dim[0] on one GPU)
+    int32_t xoff;    // global x index of local layer 0 (0 on one GPU)
     uint32_t ncells;
     uint32_t hash_n;  // the reference's `num_particles` in hash_cell (global N)
 };
@@ -64,6 +67,7 @@ struct ws_handle {
     int variant = WS_VARIANT_LISTED;  // density / near density ride in srt.pred[i].w / srt.vel[i].w
     float4 *accel = nullptr;      // acceleration in `srt` order
     uint32_t *slot_tmp = nullptr; // particle index per tentative slot
+    uint32_t *id_tmp = nullptr;   // particle id per tentative slot (canonical in-cell order)
     uint32_t *count = nullptr;    // per-cell particle count (histogram)
     uint32_t *cursor = nullptr;   // per-cell fill cursor
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
@@ -97,11 +101,12 @@ void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32
 void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);
 void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count);
 void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *bsum,
-              uint32_t nitems, uint32_t nblocks, bool zero_count);
+              uint32_t nitems, uint32_t nblocks, bool zero_count, uint32_t base);
 uint32_t wsk_scan_blocks(uint32_t nitems);
-void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n);
-void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur,
-                 const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
+void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
+                 uint32_t *id_tmp, uint32_t n);
+void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
                  const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats);
 uint32_t wsk_tile_list_words(uint32_t n);

@@ -39,7 +39,10 @@ __device__ __forceinline__ uint32_t grid_cell(const WsDev &d, float x, float y, 
     const float fy = floorf(y / d.h) - (float)d.org[1];
     const float fz = floorf(z / d.h) - (float)d.org[2];
     // fmaxf/fminf also squash NaN to the low border
-    const int gx = (int)fminf(fmaxf(fx, 0.0f), (float)(d.dim[0] - 1));
+    // x: clamped in GLOBAL grid coordinates, then shifted into this handle's local (slab) grid and
+    // clamped again so a particle that left the slab still bins inside the local tables
+    const int gxg = (int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
+    const int gx = min(max(gxg - d.xoff, 0), d.dim[0] - 1);
     const int gy = (int)fminf(fmaxf(fy, 0.0f), (float)(d.dim[1] - 1));
     const int gz = (int)fminf(fmaxf(fz, 0.0f), (float)(d.dim[2] - 1));
     return (uint32_t)((gx * d.dim[1] + gy) * d.dim[2] + gz);
@@ -189,7 +192,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan_top(uint32_t *__restrict__ bs
 template <bool ZERO>
 __global__ void __launch_bounds__(WS_BLOCK) k_scan_apply(uint32_t *__restrict__ count, uint32_t nitems,
                                                          const uint32_t *__restrict__ bsum,
-                                                         uint32_t *__restrict__ start, uint32_t *__restrict__ cursor)
+                                                         uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
+                                                         uint32_t start_offset)
 {
     uint32_t v[WS_SCAN_ITEMS];
     load_tile(count, nitems, v);
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan_apply(uint32_t *__restrict__ 
 #pragma unroll
     for (int k = 0; k < WS_SCAN_ITEMS; k++) s += v[k];
     uint32_t total;
-    uint32_t run = block_excl_scan(s, &total) + bsum[blockIdx.x];
+    uint32_t run = block_excl_scan(s, &total) + bsum[blockIdx.x] + start_offset;
     const uint32_t base = blockIdx.x * WS_SCAN_TILE + threadIdx.x * WS_SCAN_ITEMS;
 #pragma unroll
     for (int k = 0; k < WS_SCAN_ITEMS; k++) {
@@ -215,49 +219,62 @@ uint32_t wsk_scan_blocks(uint32_t nitems) { return cdiv(nitems, WS_SCAN_TILE); }
 // start_body points at the first real entry (after the guard); entry [nitems] and the
 // guards are constant and written once by the host.
 void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *bsum,
-              uint32_t nitems, uint32_t nblocks, bool zero_count)
+              uint32_t nitems, uint32_t nblocks, bool zero_count, uint32_t base)
 {
     hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(WS_BLOCK), 0, s, count, nitems, bsum);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WS_BLOCK), 0, s, bsum, nblocks);
     if (zero_count)
         hipLaunchKernelGGL(k_scan_apply<true>, dim3(nblocks), dim3(WS_BLOCK), 0, s, count, nitems, bsum, start_body,
-                           cursor);
+                           cursor, base);
     else
         hipLaunchKernelGGL(k_scan_apply<false>, dim3(nblocks), dim3(WS_BLOCK), 0, s, count, nitems, bsum, start_body,
-                           cursor);
+                           cursor, base);
 }
 
 // ---------------------------------------------------------------------------------
-// K2': counting sort by cell.  Slot assignment inside a cell uses a returning atomic
-// (arrival order), k_reorder then ranks the members of each cell by their previous
-// index, so the final order is the STABLE sort of the previous order: deterministic.
+// K2': counting sort by cell.  Slot assignment inside a cell uses a returning atomic (arrival
+// order); k_reorder then ranks the members of each cell by PARTICLE ID, so the order inside a
+// cell is canonical: it depends on neither the previous order nor, across GPUs, on the order in
+// which migrated particles arrived.  Summation order -- hence every float -- is therefore a
+// function of the particle set alone, and an N-GPU run reproduces the 1-GPU run bit for bit.
+// Slots are absolute indices into the sorted arrays (cell starts already include d.base).
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict__ keys, uint32_t *__restrict__ cursor,
-                                                      uint32_t *__restrict__ slot_tmp, uint32_t n)
+__global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict__ keys,
+                                                      const float4 *__restrict__ pos_with_id,
+                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ slot_tmp,
+                                                      uint32_t *__restrict__ id_tmp, uint32_t n)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = atomicAdd(&cursor[keys[i]], 1u);
     slot_tmp[slot] = i;
+    if (id_tmp) id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
 }
 
-void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n)
+void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
+                 uint32_t *id_tmp, uint32_t n)
 {
-    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, keys, cursor, slot_tmp, n);
+    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, keys, pos_with_id, cursor, slot_tmp,
+                       id_tmp, n);
 }
 
+// `cur` and cid_cur are indexed from the first owned particle (the caller passes offset pointers);
+// srt / cid_srt / slot_tmp / id_tmp are indexed absolutely.
 __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *__restrict__ slot_tmp,
+                                                      const uint32_t *__restrict__ id_tmp,
                                                       const uint32_t *__restrict__ cid_cur,
                                                       const uint32_t *__restrict__ start, WsSoA cur, WsSoA srt,
                                                       uint32_t *__restrict__ cid_srt)
 {
-    const uint32_t s = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (s >= d.n) return;
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (k >= d.n) return;
+    const uint32_t s = d.base + k;
     const uint32_t i = slot_tmp[s];
+    const uint32_t id = id_tmp[s];
     const uint32_t c = cid_cur[i];
     const uint32_t b = start[d.guard + c], e = start[d.guard + c + 1];
     uint32_t rank = 0;
-    for (uint32_t t = b; t < e; t++) rank += (slot_tmp[t] < i) ? 1u : 0u;
+    for (uint32_t t = b; t < e; t++) rank += (id_tmp[t] < id) ? 1u : 0u;
     const uint32_t dst = b + rank;
     srt.pos[dst] = cur.pos[i];
     srt.vel[dst] = cur.vel[i];
@@ -265,11 +282,11 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     cid_srt[dst] = c;
 }
 
-void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur,
-                 const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt)
+void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt)
 {
-    hipLaunchKernelGGL(k_reorder, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, cid_cur, start, cur,
-                       srt, cid_srt);
+    hipLaunchKernelGGL(k_reorder, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur, start,
+                       cur, srt, cid_srt);
 }
 
 // ---------------------------------------------------------------------------------
@@ -420,8 +437,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint
                                                              const uint32_t *__restrict__ cid_srt, WsSoA srt,
                                                              const uint8_t *__restrict__ mult)
 {
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
+    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.base + d.n) return;
     const float4 o = srt.pred[i];
     const int c = (int)cid_srt[i];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
@@ -448,8 +465,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
                                                            float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                            uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
 {
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
+    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.base + d.n) return;
     const float4 o = srt.pred[i];    // w = own density
     const float4 vel = srt.vel[i];   // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
@@ -556,9 +573,9 @@ __device__ __forceinline__ bool nd_particle(const WsDev &d, const uint32_t *__re
     if (tile_list) {
         const uint32_t entry = blockIdx.x / (NB_P / ND_P);
         if (entry >= tile_list[0]) return false;
-        i = tile_list[1u + entry] * NB_P + (blockIdx.x % (NB_P / ND_P)) * ND_P + threadIdx.x;
+        i = d.base + tile_list[1u + entry] * NB_P + (blockIdx.x % (NB_P / ND_P)) * ND_P + threadIdx.x;
     } else {
-        i = blockIdx.x * ND_P + threadIdx.x;
+        i = d.base + blockIdx.x * ND_P + threadIdx.x;
     }
     return true;
 }
@@ -596,8 +613,8 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], tile_list[0]);
     uint32_t i;
     if (!nd_particle(d, tile_list, i)) return;
-    const bool valid = i < d.n;
-    const uint32_t iv = valid ? i : d.n - 1u;
+    const bool valid = i < d.base + d.n;
+    const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const float4 o = srt.pred[iv];
     float density = 0.f, near_density = 0.f;
     nd_run<U, false>(
@@ -620,8 +637,8 @@ __global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *
     __shared__ uint32_t list[ND_ROWS(U) * ND_P];  // global indices of the accepted neighbours
     uint32_t i;
     if (!nd_particle(d, tile_list, i)) return;
-    const bool valid = i < d.n;
-    const uint32_t iv = valid ? i : d.n - 1u;
+    const bool valid = i < d.base + d.n;
+    const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const float4 o = srt.pred[iv];   // w = own density
     const float4 vel = srt.vel[iv];  // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
@@ -789,7 +806,7 @@ __device__ __forceinline__ bool nb_tile_run(const WsDev &d, const NbTile &t, con
 {
     NbGeo g;
     g.c_lo = (int)cid_srt[i0];  // workgroup-uniform: scalar loads
-    g.c_hi = (int)cid_srt[min(i0 + NB_P, d.n) - 1u];
+    g.c_hi = (int)cid_srt[min(i0 + NB_P, d.base + d.n) - 1u];
     g.rowz = d.dim[2];
     g.rowy = d.dim[1] * d.dim[2];
     g.guard = d.guard;
@@ -821,9 +838,9 @@ __global__ void __launch_bounds__(NB_P, 4) k_density_tiled(WsDev d, uint32_t nti
     const uint32_t tile = nb_tile_index(ntiles);
     if (tile >= ntiles) return;
     const NbTile t = nb_carve(smem);
-    const uint32_t i0 = tile * NB_P, i = i0 + threadIdx.x;
-    const bool valid = i < d.n;
-    const uint32_t iv = valid ? i : d.n - 1u;
+    const uint32_t i0 = d.base + tile * NB_P, i = i0 + threadIdx.x;
+    const bool valid = i < d.base + d.n;
+    const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const int c = (int)cid_srt[iv];
     const float4 o = srt.pred[iv];
     float density = 0.f, near_density = 0.f;
@@ -851,9 +868,9 @@ __global__ void __launch_bounds__(NB_P, 4) k_force_tiled(WsDev d, uint32_t ntile
     const uint32_t tile = nb_tile_index(ntiles);
     if (tile >= ntiles) return;
     const NbTile t = nb_carve(smem);
-    const uint32_t i0 = tile * NB_P, i = i0 + threadIdx.x;
-    const bool valid = i < d.n;
-    const uint32_t iv = valid ? i : d.n - 1u;
+    const uint32_t i0 = d.base + tile * NB_P, i = i0 + threadIdx.x;
+    const bool valid = i < d.base + d.n;
+    const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const int c = (int)cid_srt[iv];
     const float4 o = srt.pred[iv];   // w = own density
     const float4 vel = srt.vel[iv];  // w = own near density

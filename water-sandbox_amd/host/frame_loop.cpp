@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "fluid_compute.hpp"
 
@@ -36,6 +37,9 @@ int main(int argc, char **argv)
             }
             // PostUpdate / Pass: AppComputeWorker::run
             worker.run();
+            // the app renders here (~16 ms at 60 Hz); a short pause lets the asynchronous step finish so
+            // that the next frame's update() finds ready() true, as it does in the real frame loop
+            std::this_thread::sleep_for(std::chrono::milliseconds(3));
             if (f % 10 == 9) std::printf("frame %3d  y[0] = %.6f\n", f, translation[0].y);
         }
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
