@@ -84,13 +84,17 @@ typedef struct ws_particle80 {
 
 /* Placement of this handle's share of the domain.  Zero-initialise for one GPU. */
 typedef struct ws_device_cfg {
-    int32_t device;       /* HIP device ordinal */
-    uint32_t flags;       /* WS_FLAG_* */
-    uint32_t rank;        /* slab index along x, 0-based (0 for one GPU) */
-    uint32_t world_size;  /* number of slabs (0 or 1 = single GPU) */
-    uint32_t capacity;    /* max particles this handle may own (0 = n); multi-GPU
-                             handles need head-room for migration */
-    uint32_t reserved[3];
+    int32_t device;          /* HIP device ordinal */
+    uint32_t flags;          /* WS_FLAG_* */
+    uint32_t rank;           /* slab index along x, 0-based (0 for one GPU) */
+    uint32_t world_size;     /* number of slabs (0 or 1 = single GPU) */
+    uint32_t capacity;       /* slabs: max particles this handle may own (0 = 2 n_local + 2^20);
+                                head-room for particles migrating in */
+    uint32_t ghost_capacity; /* slabs: max ghost particles per face (0 = capacity / 4 + 2^16) */
+    uint32_t reserved[2];
+    void *stream;            /* hipStream_t to enqueue on, or NULL: the library creates its own.
+                                A host that moves halos with its own communication library passes
+                                that library's stream here so both are ordered on it. */
 } ws_device_cfg;
 
 #define WS_FLAG_NONE 0u
@@ -158,6 +162,46 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz);
  * before they are read, as in the reference).  Checkpoint/restore and the tests'
  * teacher forcing use this. */
 ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
+
+/* ---- multi-GPU: one handle = one x-slab of the domain, one process per GPU ------------------
+ *
+ * The domain is cut into world_size slabs along x on cell boundaries (x is the slowest axis of the
+ * cell grid, so a slab is a contiguous range of the global cell order and its boundary layers are
+ * contiguous particle ranges).  Interactions reach one cell, so a slab needs one ghost layer from
+ * each x-neighbour.  ws_step on a slab handle runs, per step:
+ *   sort own particles -> send the two boundary layers' predicted positions to the neighbours
+ *   (halo A) -> K4 -> send their densities (halo B) -> K5+K6 -> hand particles whose predicted
+ *   position left the slab to their new owner (migration).
+ * All data movement goes through the transport callbacks below (bench.py implements them with
+ * torch.distributed on the RCCL backend: send/recv with the two neighbours, one small all-gather
+ * for migration).  The particle order inside a cell is canonical (by id), so an N-slab run
+ * reproduces the single-GPU run bit for bit.  The reference has no multi-device path; this is
+ * the scale-out row of SURVEY.md 8(e). */
+typedef struct ws_transport {
+    void *ctx;
+    /* Stream-ordered exchange with the x-neighbours d = 0 (rank - 1) and d = 1 (rank + 1): send
+     * send_bytes[d] bytes from DEVICE pointer send_ptr[d], receive recv_bytes[d] bytes into DEVICE
+     * pointer recv_ptr[d].  Zero bytes = no transfer in that direction.  Returns 0 on success. */
+    int (*sendrecv)(void *ctx, void *const send_ptr[2], const uint64_t send_bytes[2], void *const recv_ptr[2],
+                    const uint64_t recv_bytes[2], void *stream);
+    /* Blocking all-gather of `count` HOST uint32 words per rank into out[world_size * count]. */
+    int (*allgather_u32)(void *ctx, const uint32_t *in, uint32_t count, uint32_t *out);
+    /* Stream-ordered all-gather of bytes_each DEVICE bytes per rank into recv_ptr[world_size * bytes_each]. */
+    int (*allgather_dev)(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream);
+} ws_transport;
+
+/* Host-only: which slab owns each position (by the x cell of floor(x / h) in the global grid, equal
+ * cell-count cuts S_r = r * nx / world_size).  out_rank holds n entries. */
+ws_status ws_slab_assign(const ws_params *params, const float *pos_xyz, uint32_t n, uint32_t world_size,
+                         uint32_t *out_rank);
+/* Create the slab cfg->rank of cfg->world_size.  pos_xyz / ids: the n_local particles this slab owns at
+ * t = 0 (as ws_slab_assign says) and their global ids; n_global: the reference's num_particles.  The
+ * transport struct is copied; its ctx must outlive the handle. */
+ws_status ws_slab_create(const ws_params *params, const float *pos_xyz, const uint32_t *ids, uint32_t n_local,
+                         uint32_t n_global, const ws_device_cfg *cfg, const ws_transport *transport, ws_handle **out);
+/* The particles this slab owns now (count varies with migration): up to cap records and their global
+ * ids, in no particular order; *n_out = number owned.  Waits for enqueued steps. */
+ws_status ws_slab_read_particles(ws_handle *h, ws_particle80 *out, uint32_t *out_ids, uint32_t cap, uint32_t *n_out);
 
 /* ---- reference-layout views of the sort (diagnostic; computed on demand by HIP
  *      kernels, never inside ws_step) ---------------------------------------------

@@ -35,14 +35,16 @@ pub struct WsParams {
 }
 
 #[repr(C)]
-#[derive(Clone, Copy, Default)]
+#[derive(Clone, Copy)]
 pub struct WsDeviceCfg {
     pub device: i32,
     pub flags: u32,
     pub rank: u32,
     pub world_size: u32,
     pub capacity: u32,
-    pub reserved: [u32; 3],
+    pub ghost_capacity: u32,
+    pub reserved: [u32; 2],
+    pub stream: *mut std::ffi::c_void,
 }
 
 #[repr(C)]

@@ -3,7 +3,7 @@ libwsfluid.so) and the host-side mirror of the reference's fluid worker interfac
 
 The directory name carries a hyphen; import it as `water_sandbox_amd` through the shim module
 at the repository root."""
-from . import build, fluid, workloads  # noqa: F401
+from . import build, fluid, slab, workloads  # noqa: F401
 from .fluid import (  # noqa: F401
     PARTICLE_DTYPE,
     FluidWorker,

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwsfluid.so")
 
 SOURCES = ["ws_kernels.hip", "ws_api.cpp"]
-HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(ROOT, "include", "wsfluid.h")]
+HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
 
 # -ffp-contract=off: every float op in the kernels is one IEEE binary32 op, written in the
 # reference WGSL's evaluation order (no FMA contraction), see ws_kernels.hip.

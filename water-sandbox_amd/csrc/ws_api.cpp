@@ -18,6 +18,9 @@ constexpr uint64_t kMaxCells = 1ull << 29;      // 3 x u32 per cell -> 6 GiB of 
 
 thread_local std::string g_create_error;
 
+void slab_free(ws_handle *h);          // ws_slab.inc
+ws_status slab_step(ws_handle *h);     // ws_slab.inc
+
 ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
 {
     char buf[512];
@@ -297,8 +300,9 @@ void free_all(ws_handle *h)
     hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
+    slab_free(h);
     if (h->done) hipEventDestroy(h->done);
-    if (h->stream) hipStreamDestroy(h->stream);
+    if (h->stream && h->own_stream) hipStreamDestroy(h->stream);
 }
 
 }  // namespace
@@ -504,6 +508,7 @@ ws_status ws_step(ws_handle *h)
 {
     if (!h) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) return slab_step(h);
     const WsDev &d = h->dev;
     hipStream_t s = h->stream;
     {
@@ -570,12 +575,20 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
     st = derive_dev(h, *params, h->n, &nd);
     if (st) return st;
     const WsDev &od = h->dev;
-    const bool regrid = memcmp(nd.org, od.org, sizeof nd.org) || memcmp(nd.dim, od.dim, sizeof nd.dim) || nd.h != od.h;
+    bool regrid = memcmp(nd.org, od.org, sizeof nd.org) || memcmp(nd.dim, od.dim, sizeof nd.dim) || nd.h != od.h;
+    if (h->slab) {
+        // keep the slab's local grid; only the global y/z extents and the radius can be compared
+        regrid = nd.h != od.h || nd.dim[1] != od.dim[1] || nd.dim[2] != od.dim[2] || nd.dim[0] != od.gdim_x ||
+                 memcmp(nd.org, od.org, sizeof nd.org);
+        nd.dim[0] = od.dim[0]; nd.gdim_x = od.gdim_x; nd.xoff = od.xoff; nd.ncells = od.ncells; nd.guard = od.guard;
+        nd.base = od.base; nd.n = od.n; nd.hash_n = od.hash_n;
+    }
     h->params = *params;
     if (!regrid) {
         h->dev = nd;  // by-value kernel argument: picked up by the next ws_step
         return WS_OK;
     }
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "a slab handle cannot re-grid (smoothing radius / container are fixed)");
     // cell size or container changed: rebuild the grid tables and re-bin the current state
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->dev = nd;
@@ -587,6 +600,7 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
 ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 {
     if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)h->n * 12;
     ws_status st = ensure_stage(h, bytes);
@@ -602,6 +616,7 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
 {
     if (!h || !out) return WS_ERR_INVALID_ARG;
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
@@ -617,6 +632,7 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
 ws_status ws_reset(ws_handle *h, const float *pos_xyz)
 {
     if (!h || !pos_xyz) return WS_ERR_INVALID_ARG;
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
     return upload_positions(h, pos_xyz);
 }
@@ -624,6 +640,7 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz)
 ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
 {
     if (!h || !in) return WS_ERR_INVALID_ARG;
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
@@ -644,6 +661,7 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
 ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, uint32_t *cell_offsets)
 {
     if (!h) return WS_ERR_INVALID_ARG;
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t n = h->n;
     hipStream_t s = h->stream;
@@ -731,3 +749,5 @@ ws_status ws_grid_dims(ws_handle *h, uint32_t dims[3])
 }
 
 }  // extern "C"
+
+#include "ws_slab.inc"

@@ -93,7 +93,28 @@ struct ws_handle {
     double prof_ms[WS_K_COUNT] = {0};
     uint64_t prof_cnt[WS_K_COUNT] = {0};
 
+    // slab (multi-GPU) state; slab == nullptr on a single-GPU handle
+    struct WsSlab *slab = nullptr;
+    bool own_stream = true;
+
     std::string err;
+};
+
+struct WsSlab {
+    ws_transport tr{};
+    uint32_t rank = 0, world = 1;
+    uint32_t n_global = 0;
+    uint32_t cap = 0, gl_cap = 0, gr_cap = 0, mig_cap = 0;
+    std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
+    uint32_t *cuts_dev = nullptr;
+    uint32_t *cnt_dev = nullptr;      // [0] stay, [1] leave, [2..2+world) leave per rank, [2+world] arrived
+    uint32_t *leave_of_rank_dev = nullptr;
+    float4 *mig_send = nullptr, *mig_all = nullptr;
+    uint32_t *tmpL = nullptr, *tmpR = nullptr;
+    uint32_t *host_pin = nullptr;     // pinned scratch for small device->host reads
+    uint32_t gL = 0, gR = 0;          // ghosts currently staged in front of / behind the owned range
+    // cumulative statistics
+    uint64_t migrated_out = 0, ghosts_in = 0;
 };
 
 // ---- kernel launchers (ws_kernels.hip) -------------------------------------------
@@ -123,3 +144,13 @@ void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, cons
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
 void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
+// slabs
+void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
+                      uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR);
+void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
+                      WsSoA stay, uint32_t *cnt, float4 *mig_send, uint32_t mig_cap);
+void wsk_migrate_accept(hipStream_t s, const float4 *mig_all, uint32_t world, uint32_t seg_records,
+                        const uint32_t *leave_of_rank, uint32_t me, WsSoA stay, uint32_t first_free, uint32_t *arrived);
+void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+                     ws_particle80 *out, uint32_t *ids);
+void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);

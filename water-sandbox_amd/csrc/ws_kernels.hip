@@ -1115,3 +1115,160 @@ void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n)
 {
     hipLaunchKernelGGL(k_iota, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, p, n);
 }
+
+// ---------------------------------------------------------------------------------
+// slab (multi-GPU) support kernels
+// ---------------------------------------------------------------------------------
+
+// After the halo exchange: cell starts of the two ghost layers (from the neighbours' start slices,
+// rebased onto this slab's ghost slots) plus the guard entries in front of / behind the table.
+//   layer 0      <- left neighbour's last owned layer, its particles sit at [base - gL, base)
+//   layer nxl-1  <- right neighbour's first owned layer, at [base + n, base + n + gR)
+__global__ void __launch_bounds__(WS_BLOCK) k_ghost_starts(uint32_t *__restrict__ start, uint32_t guard, uint32_t rowy,
+                                                           uint32_t nxl, uint32_t base, uint32_t n, uint32_t gL,
+                                                           uint32_t gR, const uint32_t *__restrict__ tmpL,
+                                                           const uint32_t *__restrict__ tmpR)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    const uint32_t front = guard + rowy;       // guard entries + layer 0
+    const uint32_t back = rowy + guard + 2;    // layer nxl-1 + end sentinel + guard entries
+    if (t < front) {
+        uint32_t v = base - gL;
+        if (t >= guard && gL) v = base - gL + (tmpL[t - guard] - tmpL[0]);
+        if (t >= guard && !gL) v = base;
+        start[t] = v;
+    } else if (t < front + back) {
+        const uint32_t j = t - front;
+        uint32_t v = base + n + gR;
+        if (j < rowy) v = gR ? base + n + (tmpR[j] - tmpR[0]) : base + n;
+        start[guard + (nxl - 1) * rowy + j] = v;
+    }
+}
+
+void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
+                      uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR)
+{
+    const uint32_t total = guard + rowy + rowy + guard + 2;
+    hipLaunchKernelGGL(k_ghost_starts, dim3(cdiv(total, WS_BLOCK)), dim3(WS_BLOCK), 0, s, start, guard, rowy, nxl, base,
+                       n, gL, gR, tmpL, tmpR);
+}
+
+// Migration, part 1: every owned particle goes either to the `stay` copy (compacted, order free:
+// the in-cell order is canonical) or into the send buffer as a 64-byte record
+// {pos+id, vel, pred, destination rank}.  cnt[0] = stayers, cnt[1] = leavers, cnt[2 + r] = leavers for rank r.
+__global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32_t *__restrict__ cuts, uint32_t world,
+                                                           uint32_t me, WsSoA cur, WsSoA stay, uint32_t *__restrict__ cnt,
+                                                           float4 *__restrict__ mig_send, uint32_t mig_cap)
+{
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (k >= d.n) return;
+    const uint32_t i = d.base + k;
+    const float4 q = cur.pred[i];
+    const float fx = floorf(q.x / d.h) - (float)d.org[0];
+    const uint32_t gxg = (uint32_t)(int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
+    uint32_t dest = 0;
+    while (dest + 1 < world && gxg >= cuts[dest + 1]) dest++;
+    if (dest == me) {
+        const uint32_t s = d.base + atomicAdd(&cnt[0], 1u);
+        stay.pos[s] = cur.pos[i];
+        stay.vel[s] = cur.vel[i];
+        stay.pred[s] = q;
+    } else {
+        const uint32_t s = atomicAdd(&cnt[1], 1u);
+        atomicAdd(&cnt[2 + dest], 1u);
+        if (s < mig_cap) {
+            mig_send[4 * (size_t)s] = cur.pos[i];
+            mig_send[4 * (size_t)s + 1] = cur.vel[i];
+            mig_send[4 * (size_t)s + 2] = q;
+            mig_send[4 * (size_t)s + 3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
+                      WsSoA stay, uint32_t *cnt, float4 *mig_send, uint32_t mig_cap)
+{
+    if (d.n == 0) return;
+    hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, stay, cnt,
+                       mig_send, mig_cap);
+}
+
+// Migration, part 2: pick this rank's arrivals out of the all-gathered send buffers
+// (world segments of seg_records records each; leave_of_rank[q] of segment q are valid).
+__global__ void __launch_bounds__(WS_BLOCK) k_migrate_accept(const float4 *__restrict__ mig_all, uint32_t world,
+                                                             uint32_t seg_records,
+                                                             const uint32_t *__restrict__ leave_of_rank, uint32_t me,
+                                                             WsSoA stay, uint32_t first_free, uint32_t *__restrict__ arrived)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (t >= world * seg_records) return;
+    const uint32_t q = t / seg_records, k = t % seg_records;
+    if (q == me || k >= leave_of_rank[q]) return;
+    const float4 *rec = mig_all + 4 * (size_t)t;
+    if (__float_as_uint(rec[3].x) != me) return;
+    const uint32_t s = first_free + atomicAdd(arrived, 1u);
+    stay.pos[s] = rec[0];
+    stay.vel[s] = rec[1];
+    stay.pred[s] = rec[2];
+}
+
+void wsk_migrate_accept(hipStream_t s, const float4 *mig_all, uint32_t world, uint32_t seg_records,
+                        const uint32_t *leave_of_rank, uint32_t me, WsSoA stay, uint32_t first_free, uint32_t *arrived)
+{
+    const uint32_t total = world * seg_records;
+    if (!total) return;
+    hipLaunchKernelGGL(k_migrate_accept, dim3(cdiv(total, WS_BLOCK)), dim3(WS_BLOCK), 0, s, mig_all, world, seg_records,
+                       leave_of_rank, me, stay, first_free, arrived);
+}
+
+// Slab readback: owned particles (state of the last step, sorted order) with their ids.
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, WsSoA srt, const float4 *__restrict__ accel,
+                                                          int have_step, ws_particle80 *__restrict__ out,
+                                                          uint32_t *__restrict__ ids)
+{
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (k >= d.n) return;
+    const uint32_t i = d.base + k;
+    const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
+    float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have_step) {
+        dp.x = srt.pred[i].w;
+        dp.y = srt.vel[i].w;
+        dp.z = d.pressure_scalar * (dp.x - d.target_density);
+        dp.w = d.near_pressure_scalar * dp.y;
+        a = accel[i];
+    }
+    float4 *rec = reinterpret_cast<float4 *>(out + k);
+    rec[0] = make_float4(p.x, p.y, p.z, 0.f);
+    rec[1] = dp;
+    rec[2] = make_float4(v.x, v.y, v.z, 0.f);
+    rec[3] = make_float4(a.x, a.y, a.z, 0.f);
+    rec[4] = make_float4(q.x, q.y, q.z, 0.f);
+    ids[k] = __float_as_uint(p.w);
+}
+
+void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+                     ws_particle80 *out, uint32_t *ids)
+{
+    if (d.n == 0) return;
+    hipLaunchKernelGGL(k_gather_slab, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, srt, accel,
+                       have_step ? 1 : 0, out, ids);
+}
+
+// upload of a slab's initial particles: ids are given explicitly
+__global__ void __launch_bounds__(WS_BLOCK) k_upload_positions_ids(const float *__restrict__ xyz,
+                                                                   const uint32_t *__restrict__ ids, WsSoA cur, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    cur.pos[i] = make_float4(x, y, z, __uint_as_float(ids[i]));
+    cur.vel[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cur.pred[i] = make_float4(x, y, z, 0.f);
+}
+
+void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_upload_positions_ids, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, xyz_dev, ids_dev, cur, n);
+}

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "ws_step", "ws_ready", "ws_sync", "ws_set_params", "ws_read_positions", "ws_read_particles",
     "ws_reset", "ws_write_particles", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
     "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
-    "ws_grid_dims", "ws_read_stats",
+    "ws_grid_dims", "ws_read_stats", "ws_slab_assign", "ws_slab_create", "ws_slab_read_particles",
 ]
 
 
@@ -70,7 +70,9 @@ class WsDeviceCfg(C.Structure):
         ("rank", C.c_uint32),
         ("world_size", C.c_uint32),
         ("capacity", C.c_uint32),
-        ("reserved", C.c_uint32 * 3),
+        ("ghost_capacity", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
+        ("stream", C.c_void_p),
     ]
 
 

@@ -1,0 +1,296 @@
+"""Multi-GPU slabs over the C ABI (include/wsfluid.h, "multi-GPU" section).
+
+Host-side plumbing only: the slab protocol itself (sort -> halo A -> K4 -> halo B -> K5+K6 ->
+migration) lives in the library (csrc/ws_slab.inc); this module supplies the transport callbacks
+it calls and a thin worker class.
+
+Transports:
+  TorchDistTransport  one process per GPU, torch.distributed: RCCL ("nccl" backend) send/recv with
+                      the two x-neighbours + all_gather for migration, a gloo group for the few
+                      control words.  This is what bench.py uses.
+  LoopbackHub         several slabs inside ONE process on ONE GPU, one host thread per slab,
+                      device-to-device copies.  Lets the one-GPU test box exercise the whole slab
+                      protocol (ghost indexing, migration, bit-exactness against one GPU).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import fluid
+
+SENDRECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                         C.POINTER(C.c_uint64), C.c_void_p)
+ALLGATHER_U32_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32))
+ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class WsTransport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_u32", ALLGATHER_U32_T),
+                ("allgather_dev", ALLGATHER_DEV_T)]
+
+
+def assign(params, positions, world_size):
+    """ws_slab_assign: the slab (rank) that owns each position at t = 0."""
+    L = fluid.load_library()
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    out = np.empty(positions.shape[0], np.uint32)
+    L.ws_slab_assign.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    st = L.ws_slab_assign(C.byref(params), positions.ctypes.data, positions.shape[0], world_size, out.ctypes.data)
+    if st != 0:
+        raise fluid.WsError(st, (L.ws_last_error(None) or b"").decode())
+    return out
+
+
+class _TransportBase:
+    """Wraps three Python methods as the C callback table; keeps the thunks alive."""
+
+    def __init__(self):
+        self.error = None
+        self._thunks = (SENDRECV_T(self._c_sendrecv), ALLGATHER_U32_T(self._c_allgather_u32),
+                        ALLGATHER_DEV_T(self._c_allgather_dev))
+        self.struct = WsTransport(None, *self._thunks)
+
+    def _guard(self, fn, *a):
+        try:
+            fn(*a)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            self.error = e
+            return 1
+
+    def _c_sendrecv(self, ctx, sp, sb, rp, rb, stream):
+        return self._guard(self.sendrecv, [sp[0], sp[1]], [sb[0], sb[1]], [rp[0], rp[1]], [rb[0], rb[1]], stream)
+
+    def _c_allgather_u32(self, ctx, inp, count, out):
+        def run():
+            res = self.allgather_u32([inp[i] for i in range(count)])
+            for i, v in enumerate(res):
+                out[i] = v
+        return self._guard(run)
+
+    def _c_allgather_dev(self, ctx, sp, rp, nbytes, stream):
+        return self._guard(self.allgather_dev, sp, rp, nbytes, stream)
+
+
+# ------------------------------------------------------------------------------------------
+class _DevMem:
+    """A device byte range exposed through __cuda_array_interface__ so torch can alias it."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+class TorchDistTransport(_TransportBase):
+    """One process per GPU.  data_group: backend "nccl" (RCCL over xGMI) for device buffers;
+    ctrl_group: a gloo group for the handful of host control words per step."""
+
+    def __init__(self, rank, world, device, data_group=None, ctrl_group=None):
+        super().__init__()
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = rank, world
+        self.device = torch.device("cuda", device)
+        self.data_group, self.ctrl_group = data_group, ctrl_group
+
+    def _tensor(self, ptr, nbytes):
+        return self.torch.as_tensor(_DevMem(ptr, nbytes), device=self.device)
+
+    def sendrecv(self, sp, sb, rp, rb, stream):
+        dist = self.dist
+        ops, keep = [], []
+        for d, peer in ((0, self.rank - 1), (1, self.rank + 1)):
+            if sb[d]:
+                t = self._tensor(sp[d], sb[d]); keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, peer, group=self.data_group))
+            if rb[d]:
+                t = self._tensor(rp[d], rb[d]); keep.append(t)
+                ops.append(dist.P2POp(dist.irecv, t, peer, group=self.data_group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()  # stream-ordered on the current stream for the nccl backend
+
+    def allgather_u32(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.int64)
+        outs = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t, group=self.ctrl_group)
+        return [int(v) for o in outs for v in o.tolist()]
+
+    def allgather_dev(self, sp, rp, nbytes, stream):
+        src = self._tensor(sp, nbytes)
+        dst = self._tensor(rp, nbytes * self.world)
+        self.dist.all_gather_into_tensor(dst, src, group=self.data_group)
+
+
+# ------------------------------------------------------------------------------------------
+class LoopbackHub:
+    """Rendezvous point for `world` slabs living in one process (one host thread each)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+    def copy(self, dst, src, nbytes):
+        if nbytes and self.hip.hipMemcpy(dst, src, nbytes, 3) != 0:  # hipMemcpyDeviceToDevice
+            raise RuntimeError("hipMemcpy failed")
+
+    def transport(self, rank):
+        return _LoopbackTransport(self, rank)
+
+
+class _LoopbackTransport(_TransportBase):
+    def __init__(self, hub, rank):
+        super().__init__()
+        self.hub, self.rank, self.world = hub, rank, hub.world
+
+    def sendrecv(self, sp, sb, rp, rb, stream):
+        hub = self.hub
+        hub.hip.hipStreamSynchronize(stream)  # my boundary data is final before anybody reads it
+        hub.slots[self.rank] = (sp, sb)
+        hub.barrier.wait()
+        if rb[0]:
+            psp, psb = hub.slots[self.rank - 1]
+            assert psb[1] == rb[0], "left neighbour sends %d bytes, I expect %d" % (psb[1], rb[0])
+            hub.copy(rp[0], psp[1], rb[0])
+        if rb[1]:
+            psp, psb = hub.slots[self.rank + 1]
+            assert psb[0] == rb[1], "right neighbour sends %d bytes, I expect %d" % (psb[0], rb[1])
+            hub.copy(rp[1], psp[0], rb[1])
+        hub.barrier.wait()  # nobody reuses a send range before every reader is done
+
+    def allgather_u32(self, values):
+        hub = self.hub
+        hub.slots[self.rank] = list(values)
+        hub.barrier.wait()
+        out = [v for r in range(self.world) for v in hub.slots[r]]
+        hub.barrier.wait()
+        return out
+
+    def allgather_dev(self, sp, rp, nbytes, stream):
+        hub = self.hub
+        hub.hip.hipStreamSynchronize(stream)
+        hub.slots[self.rank] = sp
+        hub.barrier.wait()
+        for r in range(self.world):
+            hub.copy(rp + r * nbytes, hub.slots[r], nbytes)
+        hub.barrier.wait()
+
+
+# ------------------------------------------------------------------------------------------
+class SlabWorker:
+    """One x-slab of the domain on one GPU (ws_slab_create / ws_step / ws_slab_read_particles)."""
+
+    def __init__(self, positions, ids, n_global, params, rank, world, transport, device=0, stream=None, profile=False,
+                 capacity=0, ghost_capacity=0):
+        L = self._L = fluid.load_library()
+        L.ws_slab_create.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                     C.POINTER(fluid.WsDeviceCfg), C.POINTER(WsTransport), C.POINTER(C.c_void_p)]
+        L.ws_slab_read_particles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        self.transport = transport  # keep the callback thunks alive
+        self.rank, self.world, self.n_global = rank, world, n_global
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        assert positions.shape[0] == ids.shape[0]
+        cfg = fluid.WsDeviceCfg()
+        cfg.device, cfg.rank, cfg.world_size = device, rank, world
+        cfg.flags = fluid.WS_FLAG_PROFILE if profile else 0
+        cfg.capacity, cfg.ghost_capacity = capacity, ghost_capacity
+        cfg.stream = stream
+        self.params = params
+        self._h = C.c_void_p()
+        st = L.ws_slab_create(C.byref(params), positions.ctypes.data, ids.ctypes.data, positions.shape[0], n_global,
+                              C.byref(cfg), C.byref(transport.struct), C.byref(self._h))
+        if st != 0:
+            raise fluid.WsError(st, (L.ws_last_error(None) or b"").decode())
+
+    def _check(self, st):
+        if st != 0:
+            msg = (self._L.ws_last_error(self._h) or b"").decode()
+            if self.transport.error is not None:
+                msg += " [transport: %r]" % (self.transport.error,)
+            raise fluid.WsError(st, msg)
+
+    def run(self, steps=1):
+        for _ in range(steps):
+            self._check(self._L.ws_step(self._h))
+
+    def sync(self):
+        self._check(self._L.ws_sync(self._h))
+
+    def num_owned(self):
+        return int(self._L.ws_num_particles(self._h))
+
+    def read(self):
+        """(records[n_owned], ids[n_owned]) of the particles this slab owns now."""
+        cap = self.num_owned()
+        out = np.empty(cap, fluid.PARTICLE_DTYPE)
+        ids = np.empty(cap, np.uint32)
+        n = C.c_uint32(0)
+        self._check(self._L.ws_slab_read_particles(self._h, out.ctypes.data, ids.ctypes.data, cap, C.byref(n)))
+        return out[: n.value], ids[: n.value]
+
+    def profile(self):
+        res = {}
+        for name, k in fluid.KERNEL_IDS.items():
+            ms, cnt = C.c_double(0), C.c_uint64(0)
+            self._check(self._L.ws_profile_read(self._h, k, C.byref(ms), C.byref(cnt)))
+            res[name] = (ms.value, int(cnt.value))
+        return res
+
+    def profile_reset(self):
+        self._check(self._L.ws_profile_reset(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.ws_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_loopback(positions, params, world, steps, device=0):
+    """Step `world` slabs of one domain inside this process (one thread per slab) and return the
+    particles of all slabs merged into original-id order.  Test helper for one-GPU boxes."""
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    n = positions.shape[0]
+    owner = assign(params, positions, world)
+    hub = LoopbackHub(world)
+    out = np.zeros(n, fluid.PARTICLE_DTYPE)
+    seen = np.zeros(n, np.int32)
+    errors = []
+    owned_counts = [None] * world
+
+    def body(r):
+        try:
+            sel = np.flatnonzero(owner == r).astype(np.uint32)
+            w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device)
+            w.run(steps)
+            rec, ids = w.read()
+            out[ids] = rec
+            np.add.at(seen, ids, 1)
+            owned_counts[r] = len(ids)
+            w.close()
+        except Exception as e:  # pragma: no cover - surfaced by the caller
+            errors.append((r, e))
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise RuntimeError("slab thread failed: %r" % (errors,))
+    assert np.all(seen == 1), "every particle must be owned by exactly one slab"
+    return out, owned_counts
