@@ -83,6 +83,7 @@ def load_traffic(config, dist):
 
 def main():
     args = parse_args()
+    import numpy as np
     import torch
 
     import water_sandbox_amd as ws
@@ -90,18 +91,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # WS_BENCH_FORCE_SLAB=1 runs the slab / torch.distributed path even with one rank (rehearsal on a one-GPU box)
+    distributed = world > 1 or os.environ.get("WS_BENCH_FORCE_SLAB") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
 
-    pos, params = ws.workloads.make_workload(args.config, args.dist)
-    n = pos.shape[0]
-    worker = ws.FluidWorker(pos, params, device=local_rank, profile=True)
+    if distributed:
+        # one process per GPU; each owns one x-slab of the (world x wider) domain.  Halos and migrants
+        # move through torch.distributed: backend "nccl" = RCCL over xGMI for device buffers, a gloo
+        # group for the few control words per step (DESIGN.md "Multi-GPU").
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ctrl = dist.new_group(backend="gloo")
+        # the library enqueues on the stream RCCL's point-to-point calls are ordered on: an explicit,
+        # non-default torch stream made current for the whole run (the default stream's handle is 0,
+        # which ws_device_cfg.stream reads as "create your own")
+        torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
+        pos, ids, n_global, params = ws.slab.make_dist_workload(ws, args.config, args.dist, rank, world)
+        transport = ws.slab.TorchDistTransport(rank, world, local_rank, data_group=None, ctrl_group=ctrl)
+        worker = ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
+                                    stream=torch.cuda.current_stream().cuda_stream, profile=True)
+        n_rank = n_global // world  # particles per rank at t = 0 (the single-GPU config's count)
+    else:
+        pos, params = ws.workloads.make_workload(args.config, args.dist)
+        n_global = n_rank = pos.shape[0]
+        worker = ws.FluidWorker(pos, params, device=local_rank, profile=True)
+        # HIP events bracket every kernel of the step on the library's own stream, inside the timed
+        # region (about a dozen event records per ~ms step: well under 1 % of it)
+        worker.profile_select(0xFFFFFFFF)
 
     def barrier():
         worker.sync()
@@ -109,9 +128,6 @@ def main():
         if distributed:
             dist.barrier()
 
-    # HIP events bracket every kernel of the step on the library's own stream, inside the timed
-    # region (about a dozen event records per ~ms step: well under 1 % of it)
-    worker.profile_select(0xFFFFFFFF)
     worker.run(args.warmup)
     barrier()
     worker.profile_reset()
@@ -125,17 +141,23 @@ def main():
         elapsed = float(t.item())
     prof = worker.profile()
     force_ms, force_cnt = prof["force_integrate_bin"]
-
     breakdown = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]}
+    owned = worker.num_owned() if distributed else n_rank
 
     if rank == 0:
-        steps_per_s = args.steps / elapsed
+        global_steps_per_s = args.steps / elapsed
+        # unit of work = one step of one rank's 4 194 304-particle (config-sized) share; all ranks
+        # together process `world` of them per global step (weak scaling), so the whole-job value is
+        # world x global steps/s.  At world = 1 this is plain simulation steps/s.
+        value = world * global_steps_per_s
         force_avg_s = force_ms / max(force_cnt, 1) * 1e-3
-        alg_bytes = KERNEL_ALG_BYTES["force_integrate_bin"] * n
+        alg_bytes = KERNEL_ALG_BYTES["force_integrate_bin"] * owned
         achieved = alg_bytes / force_avg_s / 1e9
+        dist_name = ("uniform cloud seed 0x%X" % ws.workloads.cloud_seed(args.config)) if args.dist == "cloud" \
+            else "cube_fluid lattice"
         out = {
             "metric": "simulation steps/sec @ N particles",
-            "value": steps_per_s,
+            "value": value,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -147,17 +169,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d particles, 3D, %s, reference default parameters"
-                % (args.config.upper(), n * world, "uniform cloud seed 0x%X" % ws.workloads.cloud_seed(args.config)
-                   if args.dist == "cloud" else "cube_fluid lattice"),
-                "particles": n * world,
+                "workload": "%s%s: %d particles, 3D, %s, reference default parameters; steps %d..%d of the trajectory"
+                % (args.config.upper(), (" x%d along x (one x-slab per GPU)" % world) if distributed else "", n_global,
+                   dist_name, args.warmup, args.warmup + args.steps),
+                "particles": n_global,
+                "particles_per_gpu": n_rank,
                 "distribution": args.dist,
                 "container": [params.ext_min[i] for i in range(3)] + [params.ext_max[i] for i in range(3)],
-                "grid_cells": list(worker.grid_dims()),
+                "value_definition": "n_gpus x global simulation steps/s (each GPU steps a %d-particle share)" % n_rank,
                 "readback_in_timed_region": False,
             },
-            "particle_steps_per_s": steps_per_s * n * world,
-            "algorithmic_GBps_step": B_ALG_STEP * n * world * steps_per_s / 1e9,
+            "global_steps_per_s": global_steps_per_s,
+            "particle_steps_per_s": global_steps_per_s * n_global,
+            "algorithmic_GBps_step": B_ALG_STEP * n_global * global_steps_per_s / 1e9,
             "roofline": {
                 "kernel": "force_integrate_bin (K5 update_pressure_force + K6 integrate + next K1 binning)",
                 "bound": "hbm",
@@ -165,15 +189,17 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(args.config, args.dist),
+                "traffic": load_traffic(args.config, args.dist) if not distributed else None,
                 "alg_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": force_avg_s * 1e3,
                 "launches_timed": force_cnt,
             },
             "kernel_ms": breakdown,
-            "stats": worker.stats(),
         }
-        if not args.no_cpu_baseline:
+        if not distributed:
+            out["config"]["grid_cells"] = list(worker.grid_dims())
+            out["stats"] = worker.stats()
+        if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(pos, params, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
@@ -183,6 +209,7 @@ def main():
         print(json.dumps(out))
     worker.close()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,41 @@
+"""N > 1 on CPU: world_size-2 gloo run of the slab protocol model (tests/dist_cpu_slab_model.py) against
+the single-domain oracle.  Floats differ only by summation order (each slab hashes into its own table)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_slab_model_matches_single_domain_oracle(oracle, ws, tmp_path):
+    from util import oracle_from_params
+
+    steps = 6
+    pattern = str(tmp_path / "rank_%d.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2", WSO_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "dist_cpu_slab_model.py"), pattern, str(steps)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    params = ws.make_params(container_size=(8.0, 5.0, 5.0), gravity=(5.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(4096, 11, list(params.ext_min), list(params.ext_max))
+    orc = oracle_from_params(oracle, pos, params)
+    for _ in range(steps):
+        orc.step(oracle.SORT_FAST)
+    got = np.zeros_like(orc.particles)
+    seen = np.zeros(len(pos), np.int32)
+    counts = []
+    for r in range(2):
+        d = np.load(pattern % r)
+        got[d["ids"]] = d["state"]
+        np.add.at(seen, d["ids"], 1)
+        counts.append(len(d["ids"]))
+    assert np.all(seen == 1), "particle conservation across migration"
+    first = np.bincount(ws.slab.assign(params, pos, 2), minlength=2)
+    assert counts != list(first), "particles must have migrated in this test"
+    for f, tol in (("position", 2e-5), ("velocity", 2e-3), ("density", 2e-3)):
+        err = np.max(np.abs(got[f].astype(np.float64) - orc.particles[f].astype(np.float64)))
+        scale = max(1.0, float(np.max(np.abs(orc.particles[f]))))
+        assert err <= tol * scale, (f, err)

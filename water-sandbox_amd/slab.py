@@ -122,7 +122,49 @@ class TorchDistTransport(_TransportBase):
     def allgather_dev(self, sp, rp, nbytes, stream):
         src = self._tensor(sp, nbytes)
         dst = self._tensor(rp, nbytes * self.world)
-        self.dist.all_gather_into_tensor(dst, src, group=self.data_group)
+        if self.dist.get_backend(self.data_group) == "nccl":
+            self.dist.all_gather_into_tensor(dst, src, group=self.data_group)
+        else:  # gloo (tests): list form
+            self.dist.all_gather(list(dst.view(self.world, nbytes).unbind(0)), src, group=self.data_group)
+
+
+def make_dist_workload(ws, config, dist_name, rank, world, chunk=1 << 22):
+    """The N-GPU benchmark workload: the single-GPU config replicated `world` times along x (lattice
+    block (ni * world) x nj x nk, container (sx * world) x sy x sz), and this rank's share of it.
+    Returns (positions_local, ids_local, n_global, params).  Generated in chunks so that no rank ever
+    holds all N x 4 M positions at once."""
+    from . import workloads
+
+    block, size = workloads.CONFIGS[config]
+    block = (block[0] * world, block[1], block[2])
+    size = (size[0] * world, size[1], size[2])
+    params = fluid.make_params(container_size=size)
+    n_global = block[0] * block[1] * block[2]
+    pos_parts, id_parts = [], []
+    if dist_name == "lattice":
+        # cube_fluid order: i (x) outermost -> generate x-planes in chunks of whole planes
+        plane = block[1] * block[2]
+        planes_per_chunk = max(1, chunk // plane)
+        full_off = np.float32(0.1) - np.float32(block[0]) * np.float32(0.1)
+        for i0 in range(0, block[0], planes_per_chunk):
+            ni = min(planes_per_chunk, block[0] - i0)
+            sub = fluid.cube_fluid(ni, block[1], block[2])  # x = i * diam + (r - ni r): re-base x exactly
+            xi = (np.arange(i0, i0 + ni, dtype=np.float32) * (np.float32(0.1) * np.float32(2.0)) + full_off)
+            sub = sub.reshape(ni, plane, 3)
+            sub[:, :, 0] = xi[:, None]
+            sub = sub.reshape(-1, 3)
+            ids = np.arange(i0 * plane, (i0 + ni) * plane, dtype=np.uint32)
+            own = assign(params, sub, world) == rank
+            pos_parts.append(sub[own]); id_parts.append(ids[own])
+    else:
+        seed = workloads.cloud_seed(config)
+        for s0 in range(0, n_global, chunk):
+            m = min(chunk, n_global - s0)
+            sub = workloads.uniform_cloud(m, seed, list(params.ext_min), list(params.ext_max), start=s0)
+            ids = np.arange(s0, s0 + m, dtype=np.uint32)
+            own = assign(params, sub, world) == rank
+            pos_parts.append(sub[own]); id_parts.append(ids[own])
+    return np.concatenate(pos_parts), np.concatenate(id_parts), n_global, params
 
 
 # ------------------------------------------------------------------------------------------
