@@ -95,6 +95,12 @@ class TorchDistTransport(_TransportBase):
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", device)
         self.data_group, self.ctrl_group = data_group, ctrl_group
+        # RCCL ("nccl") calls are ordered on the current stream; gloo (tests) is not: fence by hand
+        self.stream_ordered = dist.get_backend(data_group) == "nccl"
+
+    def _fence(self):
+        if not self.stream_ordered:
+            self.torch.cuda.synchronize(self.device)
 
     def _tensor(self, ptr, nbytes):
         return self.torch.as_tensor(_DevMem(ptr, nbytes), device=self.device)
@@ -110,8 +116,10 @@ class TorchDistTransport(_TransportBase):
                 t = self._tensor(rp[d], rb[d]); keep.append(t)
                 ops.append(dist.P2POp(dist.irecv, t, peer, group=self.data_group))
         if ops:
+            self._fence()
             for req in dist.batch_isend_irecv(ops):
                 req.wait()  # stream-ordered on the current stream for the nccl backend
+            self._fence()
 
     def allgather_u32(self, values):
         t = self.torch.tensor(values, dtype=self.torch.int64)
@@ -122,10 +130,12 @@ class TorchDistTransport(_TransportBase):
     def allgather_dev(self, sp, rp, nbytes, stream):
         src = self._tensor(sp, nbytes)
         dst = self._tensor(rp, nbytes * self.world)
-        if self.dist.get_backend(self.data_group) == "nccl":
+        if self.stream_ordered:
             self.dist.all_gather_into_tensor(dst, src, group=self.data_group)
-        else:  # gloo (tests): list form
+        else:  # gloo (tests): list form, fenced
+            self._fence()
             self.dist.all_gather(list(dst.view(self.world, nbytes).unbind(0)), src, group=self.data_group)
+            self._fence()
 
 
 def make_dist_workload(ws, config, dist_name, rank, world, chunk=1 << 22):
