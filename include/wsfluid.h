@@ -172,9 +172,9 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  *   sort own particles -> send the two boundary layers' predicted positions to the neighbours
  *   (halo A) -> K4 -> send their densities (halo B) -> K5+K6 -> hand particles whose predicted
  *   position left the slab to their new owner (migration).
- * All data movement goes through the transport callbacks below (bench.py implements them with
- * torch.distributed on the RCCL backend: send/recv with the two neighbours, one small all-gather
- * for migration).  The particle order inside a cell is canonical (by id), so an N-slab run
+ * All data movement goes through the two transport callbacks below (bench.py implements them with
+ * torch.distributed on the RCCL backend: send/recv with the two neighbours; small all-gathers carry
+ * the per-step counts and the migrating particles).  Two host syncs per step read those counts.  The particle order inside a cell is canonical (by id), so an N-slab run
  * reproduces the single-GPU run bit for bit.  The reference has no multi-device path; this is
  * the scale-out row of SURVEY.md 8(e). */
 typedef struct ws_transport {
@@ -184,8 +184,6 @@ typedef struct ws_transport {
      * pointer recv_ptr[d].  Zero bytes = no transfer in that direction.  Returns 0 on success. */
     int (*sendrecv)(void *ctx, void *const send_ptr[2], const uint64_t send_bytes[2], void *const recv_ptr[2],
                     const uint64_t recv_bytes[2], void *stream);
-    /* Blocking all-gather of `count` HOST uint32 words per rank into out[world_size * count]. */
-    int (*allgather_u32)(void *ctx, const uint32_t *in, uint32_t count, uint32_t *out);
     /* Stream-ordered all-gather of bytes_each DEVICE bytes per rank into recv_ptr[world_size * bytes_each]. */
     int (*allgather_dev)(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream);
 } ws_transport;

@@ -107,8 +107,11 @@ struct WsSlab {
     uint32_t cap = 0, gl_cap = 0, gr_cap = 0, mig_cap = 0;
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
     uint32_t *cuts_dev = nullptr;
-    uint32_t *cnt_dev = nullptr;      // [0] stay, [1] leave, [2..2+world) leave per rank, [2+world] arrived
-    uint32_t *leave_of_rank_dev = nullptr;
+    uint32_t *cnt_dev = nullptr;      // [1] leavers, [2..2+world) leavers per rank, then target / source list lengths
+    uint32_t *matrix_dev = nullptr;   // all-gathered leavers-per-destination rows (world x world)
+    uint32_t *hole = nullptr, *tgt = nullptr, *src = nullptr;  // migration index lists
+    uint32_t *bnd_dev = nullptr, *bnd_all = nullptr;           // boundary-layer start values (4 per rank)
+    bool binned = false;              // cid_cur / count describe the current owned set
     float4 *mig_send = nullptr, *mig_all = nullptr;
     uint32_t *tmpL = nullptr, *tmpR = nullptr;
     uint32_t *host_pin = nullptr;     // pinned scratch for small device->host reads
@@ -148,9 +151,13 @@ void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
 void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
                       uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR);
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
-                      WsSoA stay, uint32_t *cnt, float4 *mig_send, uint32_t mig_cap);
-void wsk_migrate_accept(hipStream_t s, const float4 *mig_all, uint32_t world, uint32_t seg_records,
-                        const uint32_t *leave_of_rank, uint32_t me, WsSoA stay, uint32_t first_free, uint32_t *arrived);
+                      uint32_t *cid_cur, uint32_t *count, uint32_t *cnt, uint32_t *hole, float4 *mig_send,
+                      uint32_t mig_cap);
+void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t n_old, uint32_t n_new, uint32_t nleave, uint32_t narrive,
+                      const uint32_t *hole, const float4 *mig_all, uint32_t world, uint32_t seg_records,
+                      const uint32_t *leave_matrix, uint32_t me, uint32_t *tgt, uint32_t *src, uint32_t *cnt, WsSoA cur,
+                      uint32_t *cid_cur, uint32_t *count);
+void wsk_pick4(hipStream_t s, const uint32_t *start, const uint32_t idx[4], uint32_t *out);
 void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids);
 void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);

@@ -1153,12 +1153,20 @@ void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t r
                        n, gL, gR, tmpL, tmpR);
 }
 
-// Migration, part 1: every owned particle goes either to the `stay` copy (compacted, order free:
-// the in-cell order is canonical) or into the send buffer as a 64-byte record
-// {pos+id, vel, pred, destination rank}.  cnt[0] = stayers, cnt[1] = leavers, cnt[2 + r] = leavers for rank r.
+// Migration.  Particles stay where they are in `cur`; only the ones that left the slab (and the few
+// moved to close the holes they leave) are touched, and the cell histogram built by the force
+// kernel is corrected incrementally -- O(leavers + arrivals) work per step, not O(n).
+// cnt[1] = leavers, cnt[2 + r] = leavers for rank r, cnt[2 + world] / cnt[3 + world] = target / source
+// list lengths.  Order is free everywhere here: the sort puts each cell in canonical id order.
+#define WS_DEAD 0xFFFFFFFFu
+
+// part 1: find the leavers; write their 64-byte records {pos+id, vel, pred, destination rank}, remember
+// the holes they leave, take them out of the histogram
 __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32_t *__restrict__ cuts, uint32_t world,
-                                                           uint32_t me, WsSoA cur, WsSoA stay, uint32_t *__restrict__ cnt,
-                                                           float4 *__restrict__ mig_send, uint32_t mig_cap)
+                                                           uint32_t me, WsSoA cur, uint32_t *__restrict__ cid_cur,
+                                                           uint32_t *__restrict__ count, uint32_t *__restrict__ cnt,
+                                                           uint32_t *__restrict__ hole, float4 *__restrict__ mig_send,
+                                                           uint32_t mig_cap)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (k >= d.n) return;
@@ -1168,57 +1176,128 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32
     const uint32_t gxg = (uint32_t)(int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
     uint32_t dest = 0;
     while (dest + 1 < world && gxg >= cuts[dest + 1]) dest++;
-    if (dest == me) {
-        const uint32_t s = d.base + atomicAdd(&cnt[0], 1u);
-        stay.pos[s] = cur.pos[i];
-        stay.vel[s] = cur.vel[i];
-        stay.pred[s] = q;
-    } else {
-        const uint32_t s = atomicAdd(&cnt[1], 1u);
-        atomicAdd(&cnt[2 + dest], 1u);
-        if (s < mig_cap) {
-            mig_send[4 * (size_t)s] = cur.pos[i];
-            mig_send[4 * (size_t)s + 1] = cur.vel[i];
-            mig_send[4 * (size_t)s + 2] = q;
-            mig_send[4 * (size_t)s + 3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
-        }
+    if (dest == me) return;
+    const uint32_t s = atomicAdd(&cnt[1], 1u);
+    atomicAdd(&cnt[2 + dest], 1u);
+    atomicSub(&count[cid_cur[i]], 1u);
+    cid_cur[i] = WS_DEAD;
+    if (s < mig_cap) {
+        hole[s] = i;
+        mig_send[4 * (size_t)s] = cur.pos[i];
+        mig_send[4 * (size_t)s + 1] = cur.vel[i];
+        mig_send[4 * (size_t)s + 2] = q;
+        mig_send[4 * (size_t)s + 3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
     }
 }
 
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
-                      WsSoA stay, uint32_t *cnt, float4 *mig_send, uint32_t mig_cap)
+                      uint32_t *cid_cur, uint32_t *count, uint32_t *cnt, uint32_t *hole, float4 *mig_send,
+                      uint32_t mig_cap)
 {
     if (d.n == 0) return;
-    hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, stay, cnt,
-                       mig_send, mig_cap);
+    hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, cid_cur,
+                       count, cnt, hole, mig_send, mig_cap);
 }
 
-// Migration, part 2: pick this rank's arrivals out of the all-gathered send buffers
-// (world segments of seg_records records each; leave_of_rank[q] of segment q are valid).
-__global__ void __launch_bounds__(WS_BLOCK) k_migrate_accept(const float4 *__restrict__ mig_all, uint32_t world,
-                                                             uint32_t seg_records,
-                                                             const uint32_t *__restrict__ leave_of_rank, uint32_t me,
-                                                             WsSoA stay, uint32_t first_free, uint32_t *__restrict__ arrived)
+// part 2: the owned range shrinks / grows from n_old to n_new.  Targets = holes below n_new (+ the new
+// slots when growing); sources = this rank's arrivals in the all-gathered records (tagged with the top
+// bit) + surviving particles above n_new.  Both lists come out equally long.
+__global__ void __launch_bounds__(WS_BLOCK) k_migrate_collect(uint32_t base, uint32_t n_old, uint32_t n_new, uint32_t nleave,
+                                                              const uint32_t *__restrict__ hole,
+                                                              const uint32_t *__restrict__ cid_cur,
+                                                              const float4 *__restrict__ mig_all, uint32_t world,
+                                                              uint32_t seg_records,
+                                                              const uint32_t *__restrict__ leave_matrix, uint32_t me,
+                                                              uint32_t *__restrict__ tgt, uint32_t *__restrict__ src,
+                                                              uint32_t *__restrict__ cnt)
 {
-    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (t >= world * seg_records) return;
-    const uint32_t q = t / seg_records, k = t % seg_records;
-    if (q == me || k >= leave_of_rank[q]) return;
-    const float4 *rec = mig_all + 4 * (size_t)t;
-    if (__float_as_uint(rec[3].x) != me) return;
-    const uint32_t s = first_free + atomicAdd(arrived, 1u);
-    stay.pos[s] = rec[0];
-    stay.vel[s] = rec[1];
-    stay.pred[s] = rec[2];
+    uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    uint32_t *n_tgt = cnt + 2 + world, *n_src = cnt + 3 + world;
+    if (t < nleave) {  // A: holes
+        const uint32_t i = hole[t];
+        if (i < base + n_new) tgt[atomicAdd(n_tgt, 1u)] = i;
+        return;
+    }
+    t -= nleave;
+    const uint32_t tail = n_old > n_new ? n_old - n_new : 0u;
+    if (t < tail) {  // B: survivors above the new end
+        const uint32_t i = base + n_new + t;
+        if (cid_cur[i] != WS_DEAD) src[atomicAdd(n_src, 1u)] = i;
+        return;
+    }
+    t -= tail;
+    const uint32_t grow = n_new > n_old ? n_new - n_old : 0u;
+    if (t < grow) {  // C: fresh slots when the owned range grows
+        tgt[atomicAdd(n_tgt, 1u)] = base + n_old + t;
+        return;
+    }
+    t -= grow;
+    if (t < world * seg_records) {  // D: arrivals addressed to this rank
+        const uint32_t q = t / seg_records, k = t % seg_records;
+        if (q == me) return;
+        uint32_t lq = 0;
+        for (uint32_t r = 0; r < world; r++) lq += leave_matrix[q * world + r];
+        if (k >= lq) return;
+        if (__float_as_uint(mig_all[4 * (size_t)t + 3].x) == me) src[atomicAdd(n_src, 1u)] = 0x80000000u | t;
+    }
 }
 
-void wsk_migrate_accept(hipStream_t s, const float4 *mig_all, uint32_t world, uint32_t seg_records,
-                        const uint32_t *leave_of_rank, uint32_t me, WsSoA stay, uint32_t first_free, uint32_t *arrived)
+__global__ void __launch_bounds__(WS_BLOCK) k_migrate_apply(WsDev d, const uint32_t *__restrict__ tgt,
+                                                            const uint32_t *__restrict__ src,
+                                                            const uint32_t *__restrict__ cnt, uint32_t world, WsSoA cur,
+                                                            uint32_t *__restrict__ cid_cur, uint32_t *__restrict__ count,
+                                                            const float4 *__restrict__ mig_all)
 {
-    const uint32_t total = world * seg_records;
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (k >= cnt[2 + world]) return;
+    const uint32_t to = tgt[k], from = src[k];
+    if (from & 0x80000000u) {
+        const float4 *rec = mig_all + 4 * (size_t)(from & 0x7FFFFFFFu);
+        const float4 q = rec[2];
+        cur.pos[to] = rec[0];
+        cur.vel[to] = rec[1];
+        cur.pred[to] = q;
+        const uint32_t c = grid_cell(d, q.x, q.y, q.z);
+        cid_cur[to] = c;
+        atomicAdd(&count[c], 1u);
+    } else {
+        cur.pos[to] = cur.pos[from];
+        cur.vel[to] = cur.vel[from];
+        cur.pred[to] = cur.pred[from];
+        cid_cur[to] = cid_cur[from];
+    }
+}
+
+void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t n_old, uint32_t n_new, uint32_t nleave, uint32_t narrive,
+                      const uint32_t *hole, const float4 *mig_all, uint32_t world, uint32_t seg_records,
+                      const uint32_t *leave_matrix, uint32_t me, uint32_t *tgt, uint32_t *src, uint32_t *cnt, WsSoA cur,
+                      uint32_t *cid_cur, uint32_t *count)
+{
+    const uint32_t tail = n_old > n_new ? n_old - n_new : 0u, grow = n_new > n_old ? n_new - n_old : 0u;
+    const uint32_t total = nleave + tail + grow + (narrive ? world * seg_records : 0u);
     if (!total) return;
-    hipLaunchKernelGGL(k_migrate_accept, dim3(cdiv(total, WS_BLOCK)), dim3(WS_BLOCK), 0, s, mig_all, world, seg_records,
-                       leave_of_rank, me, stay, first_free, arrived);
+    hipLaunchKernelGGL(k_migrate_collect, dim3(cdiv(total, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d.base, n_old, n_new, nleave,
+                       hole, cid_cur, mig_all, world, narrive ? seg_records : 0u, leave_matrix, me, tgt, src, cnt);
+    const uint32_t pairs = nleave > narrive ? nleave : narrive;
+    hipLaunchKernelGGL(k_migrate_apply, dim3(cdiv(pairs, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, tgt, src, cnt, world, cur,
+                       cid_cur, count, mig_all);
+}
+
+// the four cell-start values that delimit the two boundary layers, packed for the all-gather
+__global__ void k_pick4(const uint32_t *__restrict__ start, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3,
+                        uint32_t *__restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        out[0] = start[i0];
+        out[1] = start[i1];
+        out[2] = start[i2];
+        out[3] = start[i3];
+    }
+}
+
+void wsk_pick4(hipStream_t s, const uint32_t *start, const uint32_t idx[4], uint32_t *out)
+{
+    hipLaunchKernelGGL(k_pick4, dim3(1), dim3(64), 0, s, start, idx[0], idx[1], idx[2], idx[3], out);
 }
 
 // Slab readback: owned particles (state of the last step, sorted order) with their ids.

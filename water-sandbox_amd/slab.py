@@ -26,8 +26,7 @@ ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_u
 
 
 class WsTransport(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_u32", ALLGATHER_U32_T),
-                ("allgather_dev", ALLGATHER_DEV_T)]
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_dev", ALLGATHER_DEV_T)]
 
 
 def assign(params, positions, world_size):
@@ -47,8 +46,7 @@ class _TransportBase:
 
     def __init__(self):
         self.error = None
-        self._thunks = (SENDRECV_T(self._c_sendrecv), ALLGATHER_U32_T(self._c_allgather_u32),
-                        ALLGATHER_DEV_T(self._c_allgather_dev))
+        self._thunks = (SENDRECV_T(self._c_sendrecv), ALLGATHER_DEV_T(self._c_allgather_dev))
         self.struct = WsTransport(None, *self._thunks)
 
     def _guard(self, fn, *a):
