@@ -297,7 +297,7 @@ void free_all(ws_handle *h)
     hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
     hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
+    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->accept_mask); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
     slab_free(h);
@@ -475,6 +475,8 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->id_tmp, (size_t)n * 4));
+    h->mask_stride = n;
+    CREATE_HIP(hipMalloc(&h->accept_mask, (size_t)wsk_mask_words() * h->mask_stride * 4));
     CREATE_HIP(hipMalloc(&h->tile_list, (size_t)wsk_tile_list_words(n) * 4));
     CREATE_HIP(hipMemset(h->tile_list, 0, 4));
     CREATE_HIP(hipMalloc(&h->stats, 64));
@@ -525,12 +527,13 @@ ws_status ws_step(ws_handle *h)
     }
     {
         Prof p(h, WS_K_DENSITY);
-        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->tile_list, h->stats);
+        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->tile_list, h->stats, h->accept_mask,
+                    h->mask_stride);
     }
     {
         Prof p(h, WS_K_FORCE);
         wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->tile_list);
+                  h->variant, h->tile_list, h->accept_mask, h->mask_stride);
     }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));

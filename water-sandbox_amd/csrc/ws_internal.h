@@ -73,6 +73,8 @@ struct ws_handle {
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
     uint32_t *bsum = nullptr;     // scan block sums
     uint32_t nscan_blocks = 0;
+    uint32_t *accept_mask = nullptr;  // [ND_MASK_WORDS][mask_stride]: K4's accept bits per candidate, read by K5
+    uint32_t mask_stride = 0;
     uint32_t *tile_list = nullptr; // [0] = tiles handed to the listed kernels this step, [1..] = their ids
     uint32_t *stats = nullptr;    // device counters: [0]/[1] density/force tiles that overflowed LDS
     uint8_t *mult = nullptr;      // 27 stencil multiplicities (hash aliasing), device
@@ -132,11 +134,13 @@ void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id,
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
                  const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats);
+                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats, uint32_t *mask,
+                 uint32_t mask_stride);
+uint32_t wsk_mask_words(void);
 uint32_t wsk_tile_list_words(uint32_t n);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant,
-               const uint32_t *tile_list);
+               const uint32_t *tile_list, const uint32_t *mask, uint32_t mask_stride);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
                           ws_particle80 *out, uint32_t n);

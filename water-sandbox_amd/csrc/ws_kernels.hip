@@ -515,9 +515,14 @@ struct NbRange3 {
     uint32_t b0, e0, b1, e1, b2, e2;  // the three runs [b, e) of the plane, in visit order
 };
 
-template <int K, int U, class Fetch, class Push, class Phase2>
+struct NbNoNote {  // note(nvalid, bits): a trip tested `nvalid` candidates; bit u of `bits` = candidate u accepted
+    __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
+};
+
+template <int K, int U, class Fetch, class Push, class Phase2, class Note>
 __device__ __forceinline__ void nb_run_phase1(const WsDev &d, float4 o, uint32_t j, uint32_t e, bool skip_self,
-                                              uint32_t self_a, uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2)
+                                              uint32_t self_a, uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2,
+                                              Note &&note)
 {
     // One contiguous run [j, e): candidate addresses are j, j+1, ... (the loads of a trip differ
     // only by an immediate offset).  Lanes past their run's end keep loading in-bounds slots
@@ -528,6 +533,7 @@ __device__ __forceinline__ void nb_run_phase1(const WsDev &d, float4 o, uint32_t
 #pragma unroll
             for (int u = 0; u < U; u++) q[u] = fetch(j + u);
             __builtin_amdgcn_sched_barrier(0);  // all U loads are issued before any is consumed
+            uint32_t bits = 0;
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const float ex = q[u].x - o.x, ey = q[u].y - o.y, ez = q[u].z - o.z;
@@ -536,7 +542,9 @@ __device__ __forceinline__ void nb_run_phase1(const WsDev &d, float4 o, uint32_t
                 const bool acc = (j + u < e) && !(d2 > d.d2_accept) && !(skip_self && j + u == self_a);
                 push(cnt, j + u, d2);
                 cnt += acc ? 1u : 0u;
+                bits |= (acc ? 1u : 0u) << u;
             }
+            note(min((uint32_t)U, e - j), bits);
             j += U;
         }
         if (!__ballot(cnt >= (uint32_t)K && j < e)) break;  // nobody is blocked on a full list
@@ -545,13 +553,14 @@ __device__ __forceinline__ void nb_run_phase1(const WsDev &d, float4 o, uint32_t
     }
 }
 
-template <int K, int U, class Fetch, class Push, class Phase2>
+template <int K, int U, class Fetch, class Push, class Phase2, class Note = NbNoNote>
 __device__ __forceinline__ void nb_plane_phase1(const WsDev &d, float4 o, NbRange3 r, bool skip_self, uint32_t self_a,
-                                                uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2)
+                                                uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2,
+                                                Note &&note = NbNoNote())
 {
-    nb_run_phase1<K, U>(d, o, r.b0, r.e0, false, self_a, cnt, fetch, push, phase2);
-    nb_run_phase1<K, U>(d, o, r.b1, r.e1, skip_self, self_a, cnt, fetch, push, phase2);  // own cell is in the middle run
-    nb_run_phase1<K, U>(d, o, r.b2, r.e2, false, self_a, cnt, fetch, push, phase2);
+    nb_run_phase1<K, U>(d, o, r.b0, r.e0, false, self_a, cnt, fetch, push, phase2, note);
+    nb_run_phase1<K, U>(d, o, r.b1, r.e1, skip_self, self_a, cnt, fetch, push, phase2, note);  // own cell: middle run
+    nb_run_phase1<K, U>(d, o, r.b2, r.e2, false, self_a, cnt, fetch, push, phase2, note);
 }
 
 // ---------------------------------------------------------------------------------
@@ -580,11 +589,83 @@ __device__ __forceinline__ bool nd_particle(const WsDev &d, const uint32_t *__re
     return true;
 }
 
-template <int U, bool SKIP_SELF, class Push, class Phase2>
-__device__ __forceinline__ void nd_run(const WsDev &d, const uint32_t *__restrict__ start, int c, uint32_t i, bool valid,
-                                       float4 o, const float4 *__restrict__ pred, Push &&push, Phase2 &&phase2)
+// K4 and K5 accept exactly the same candidates (same positions, same threshold; K5 only drops the
+// particle itself), and they enumerate them in the same order.  So K4 records, per particle, ONE BIT
+// PER CANDIDATE in visit order (accept_mask[word][particle], coalesced), and K5 replaces its whole
+// radius-test phase by a walk over the set bits: ~18 instructions per candidate become ~8 per ACCEPTED
+// candidate, for (candidates / 8) bytes of mask traffic.  Particles with more than 32 * ND_MASK_WORDS
+// candidates (none in the benchmark states) do the full test again in K5.
+#define ND_MASK_WORDS 32
+
+struct NdRuns {
+    uint32_t b[9], e[9];
+    uint32_t total;
+};
+
+__device__ __forceinline__ NdRuns nd_runs(const WsDev &d, const uint32_t *__restrict__ start, int c, bool valid)
 {
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    NdRuns r;
+    r.total = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int cc = d.guard + c + (k / 3 - 1) * rowy + (k % 3 - 1) * rowz;
+        r.b[k] = valid ? start[cc - 1] : 0u;
+        r.e[k] = valid ? start[cc + 2] : 0u;
+        r.total += r.e[k] - r.b[k];
+    }
+    return r;
+}
+
+template <int U, bool SKIP_SELF, class Push, class Phase2, class Note>
+__device__ __forceinline__ void nd_run(const WsDev &d, const NdRuns &R, uint32_t i, float4 o,
+                                       const float4 *__restrict__ pred, Push &&push, Phase2 &&phase2, Note &&note)
+{
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
+        const NbRange3 r = {R.b[3 * p], R.e[3 * p], R.b[3 * p + 1], R.e[3 * p + 1], R.b[3 * p + 2], R.e[3 * p + 2]};
+        nb_plane_phase1<ND_K, U>(
+            d, o, r, SKIP_SELF && p == 1, i, cnt, [&](uint32_t a) { return pred[a]; }, push, phase2, note);
+    }
+    phase2(cnt);
+}
+
+template <int U>
+__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ tile_list,
+                                                         const uint32_t *__restrict__ start,
+                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                         uint32_t *__restrict__ accept_mask, uint32_t mask_stride,
+                                                         uint32_t *__restrict__ stats)
+{
+    __shared__ float list[ND_ROWS(U) * ND_P];  // K4's phase 2 needs only d2: the list holds it
+    if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], tile_list[0]);
+    uint32_t i;
+    if (!nd_particle(d, tile_list, i)) return;
+    const bool valid = i < d.base + d.n;
+    const uint32_t iv = valid ? i : d.base + d.n - 1u;
+    const float4 o = srt.pred[iv];
+    const int c = (int)cid_srt[iv];
+    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    float density = 0.f, near_density = 0.f;
+    // accept mask of this particle: bit `seq` = candidate number seq in visit order.  Trips append up to
+    // U bits to a 64-bit accumulator; a full low word goes out (coalesced across lanes: [word][particle]).
+    unsigned long long acc64 = 0;
+    uint32_t seq = 0;
+    uint32_t *mrow = accept_mask + iv;
+    auto push = [&](uint32_t slot, uint32_t, float d2) { list[slot * ND_P + threadIdx.x] = d2; };
+    auto phase2 = [&](uint32_t cnt) {
+        for (uint32_t k = 0; k < cnt; k++) density_pair(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
+    };
+    auto note = [&](uint32_t nvalid, uint32_t bits) {
+        acc64 |= (unsigned long long)bits << (seq & 31u);
+        const uint32_t w0 = seq >> 5;
+        seq += nvalid;
+        if ((seq >> 5) != w0) {
+            if (w0 < ND_MASK_WORDS) mrow[(size_t)w0 * mask_stride] = (uint32_t)acc64;
+            acc64 >>= 32;
+        }
+    };
     uint32_t cnt = 0;
     for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
         const int cc = d.guard + c + (p - 1) * rowy;
@@ -598,33 +679,13 @@ __device__ __forceinline__ void nd_run(const WsDev &d, const uint32_t *__restric
             r.e2 = start[cc + rowz + 2];
         }
         nb_plane_phase1<ND_K, U>(
-            d, o, r, SKIP_SELF && p == 1, i, cnt, [&](uint32_t a) { return pred[a]; }, push, phase2);
+            d, o, r, false, i, cnt, [&](uint32_t a) { return srt.pred[a]; }, push, phase2, note);
     }
     phase2(cnt);
-}
-
-template <int U>
-__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ tile_list,
-                                                         const uint32_t *__restrict__ start,
-                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                         uint32_t *__restrict__ stats)
-{
-    __shared__ float list[ND_ROWS(U) * ND_P];  // K4's phase 2 needs only d2: the list holds it
-    if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], tile_list[0]);
-    uint32_t i;
-    if (!nd_particle(d, tile_list, i)) return;
-    const bool valid = i < d.base + d.n;
-    const uint32_t iv = valid ? i : d.base + d.n - 1u;
-    const float4 o = srt.pred[iv];
-    float density = 0.f, near_density = 0.f;
-    nd_run<U, false>(
-        d, start, (int)cid_srt[iv], i, valid, o, srt.pred,
-        [&](uint32_t slot, uint32_t, float d2) { list[slot * ND_P + threadIdx.x] = d2; },
-        [&](uint32_t cnt) {
-            for (uint32_t k = 0; k < cnt; k++)
-                density_pair(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
-        });
-    if (valid) density_store(density, near_density, i, srt);
+    if (valid) {
+        if ((seq & 31u) && (seq >> 5) < ND_MASK_WORDS) mrow[(size_t)(seq >> 5) * mask_stride] = (uint32_t)acc64;
+        density_store(density, near_density, i, srt);
+    }
 }
 
 template <int U>
@@ -632,7 +693,8 @@ __global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *
                                                        const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                       uint32_t *__restrict__ count)
+                                                       uint32_t *__restrict__ count,
+                                                       const uint32_t *__restrict__ accept_mask, uint32_t mask_stride)
 {
     __shared__ uint32_t list[ND_ROWS(U) * ND_P];  // global indices of the accepted neighbours
     uint32_t i;
@@ -644,30 +706,66 @@ __global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
     const float near_pressure = d.near_pressure_scalar * vel.w;
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    nd_run<U, true>(
-        d, start, (int)cid_srt[iv], i, valid, o, srt.pred,
-        [&](uint32_t slot, uint32_t a, float) { list[slot * ND_P + threadIdx.x] = a; },
-        [&](uint32_t cnt) {
-            // two 16-B gathers per accepted neighbour ({pred, density}, {vel, near density}),
-            // issued one list entry ahead of the arithmetic that consumes them
-            float4 q_next = o, nvel_next = vel;
-            if (cnt > 0) {
-                const uint32_t j = list[threadIdx.x];
+    auto phase2 = [&](uint32_t cnt) {
+        // two 16-B gathers per accepted neighbour ({pred, density}, {vel, near density}),
+        // issued one list entry ahead of the arithmetic that consumes them
+        float4 q_next = o, nvel_next = vel;
+        if (cnt > 0) {
+            const uint32_t j = list[threadIdx.x];
+            q_next = srt.pred[j];
+            nvel_next = srt.vel[j];
+        }
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float4 q = q_next, nvel = nvel_next;
+            if (k + 1 < cnt) {
+                const uint32_t j = list[(k + 1) * ND_P + threadIdx.x];
                 q_next = srt.pred[j];
                 nvel_next = srt.vel[j];
             }
-            for (uint32_t k = 0; k < cnt; k++) {
-                const float4 q = q_next, nvel = nvel_next;
-                if (k + 1 < cnt) {
-                    const uint32_t j = list[(k + 1) * ND_P + threadIdx.x];
-                    q_next = srt.pred[j];
-                    nvel_next = srt.vel[j];
+            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+            force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
+                       1u);
+        }
+    };
+    auto push = [&](uint32_t slot, uint32_t a, float) { list[slot * ND_P + threadIdx.x] = a; };
+    const NdRuns R = nd_runs(d, start, (int)cid_srt[iv], valid);
+    // wave-uniform choice: if every lane's candidates fit the mask, walk K4's accept bits; else test again
+    if (!__ballot(R.total > 32u * ND_MASK_WORDS)) {
+        const uint32_t *mrow = accept_mask + iv;
+        uint32_t cnt = 0, seq0 = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const uint32_t b = R.b[r], end = seq0 + (R.e[r] - b);
+            uint32_t s = seq0, word = 0, jbase = 0;  // word: accepted bits still pending in the current chunk
+            for (;;) {
+                while (cnt < (uint32_t)ND_K) {
+                    if (word == 0) {
+                        if (s >= end) break;
+                        const uint32_t off = s & 31u, nb = min(32u - off, end - s);
+                        word = mrow[(size_t)(s >> 5) * mask_stride] >> off;
+                        if (nb < 32u) word &= (1u << nb) - 1u;
+                        jbase = b + (s - seq0);
+                        s += nb;
+                        continue;
+                    }
+                    const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+                    word &= word - 1u;
+                    const uint32_t j = jbase + bit;
+                    if (j != i) {  // `particle_index == neighbour_index`, simulation.wgsl:232
+                        push(cnt, j, 0.f);
+                        cnt++;
+                    }
                 }
-                const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-                force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure,
-                           acc, 1u);
+                if (!__ballot(cnt >= (uint32_t)ND_K && (word != 0u || s < end))) break;
+                phase2(cnt);
+                cnt = 0;
             }
-        });
+            seq0 = end;
+        }
+        phase2(cnt);
+    } else {
+        nd_run<U, true>(d, R, i, o, srt.pred, push, phase2, NbNoNote());
+    }
     if (valid) force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
@@ -929,30 +1027,34 @@ static int nd_unroll()
 }
 
 static void launch_density_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
-                                  const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, uint32_t *stats)
+                                  const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, uint32_t *mask,
+                                  uint32_t mask_stride, uint32_t *stats)
 {
     switch (nd_unroll()) {
-        case 2: hipLaunchKernelGGL(k_density_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, stats); break;
-        case 8: hipLaunchKernelGGL(k_density_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, stats); break;
-        default: hipLaunchKernelGGL(k_density_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, stats); break;
+        case 2: hipLaunchKernelGGL(k_density_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, mask, mask_stride, stats); break;
+        case 8: hipLaunchKernelGGL(k_density_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, mask, mask_stride, stats); break;
+        default: hipLaunchKernelGGL(k_density_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, mask, mask_stride, stats); break;
     }
 }
 
 static void launch_force_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
                                 const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out, float4 *accel,
-                                uint32_t *cid_out, uint32_t *count)
+                                uint32_t *cid_out, uint32_t *count, const uint32_t *mask, uint32_t mask_stride)
 {
     switch (nd_unroll()) {
-        case 2: hipLaunchKernelGGL(k_force_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count); break;
-        case 8: hipLaunchKernelGGL(k_force_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count); break;
-        default: hipLaunchKernelGGL(k_force_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count); break;
+        case 2: hipLaunchKernelGGL(k_force_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride); break;
+        case 8: hipLaunchKernelGGL(k_force_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride); break;
+        default: hipLaunchKernelGGL(k_force_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride); break;
     }
 }
 
 // tile_list (variant "tiled" only): [0] = number of tiles handed to the listed kernels this
 // step (zeroed here), [1..] = their indices
+uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
+
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats)
+                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats, uint32_t *mask,
+                 uint32_t mask_stride)
 {
     if (alias || variant == WS_VARIANT_SIMPLE) {
         if (alias)
@@ -967,15 +1069,15 @@ void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uin
         hipMemsetAsync(tile_list, 0, 4, s);
         hipLaunchKernelGGL(k_density_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
                            cid_srt, srt, tile_list);
-        launch_density_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, stats);
+        launch_density_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, mask, mask_stride, stats);
     } else {
-        launch_density_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, stats);
+        launch_density_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, mask, mask_stride, stats);
     }
 }
 
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant,
-               const uint32_t *tile_list)
+               const uint32_t *tile_list, const uint32_t *mask, uint32_t mask_stride)
 {
     if (alias || variant == WS_VARIANT_SIMPLE) {
         if (alias)
@@ -989,9 +1091,10 @@ void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint3
         const uint32_t ntiles = cdiv(d.n, NB_P);
         hipLaunchKernelGGL(k_force_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
                            cid_srt, srt, out, accel, cid_out, count);
-        launch_force_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, out, accel, cid_out, count);
+        launch_force_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask,
+                            mask_stride);
     } else {
-        launch_force_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, out, accel, cid_out, count);
+        launch_force_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride);
     }
 }
 
