@@ -202,6 +202,35 @@ ws_status upload_mult(ws_handle *h)
     return WS_OK;
 }
 
+// The per-frame readback (update(), src/fluid_compute.rs:478) lands in the same host buffer frame after
+// frame.  A destination seen twice in a row is page-locked (hipHostRegister) so that the device->host copy
+// runs at PCIe rate instead of through the runtime's pageable staging; it is released when another buffer
+// shows up or the handle is destroyed.  Failure to pin is not an error: the copy just stays pageable.
+void unpin_destination(ws_handle *h)
+{
+    if (h->pinned_dst) hipHostUnregister(h->pinned_dst);
+    h->pinned_dst = nullptr;
+    h->pinned_bytes = 0;
+}
+
+void pin_destination(ws_handle *h, void *dst, size_t bytes)
+{
+    if (h->pinned_dst == dst && h->pinned_bytes >= bytes) return;
+    if (h->last_dst == dst && h->last_dst_bytes == bytes) {  // second call in a row with this buffer
+        unpin_destination(h);
+        if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) {
+            h->pinned_dst = dst;
+            h->pinned_bytes = bytes;
+        } else {
+            (void)hipGetLastError();  // clear the sticky error: not fatal
+        }
+    } else if (h->pinned_dst) {
+        unpin_destination(h);
+    }
+    h->last_dst = dst;
+    h->last_dst_bytes = bytes;
+}
+
 ws_status ensure_stage(ws_handle *h, size_t bytes)
 {
     if (h->stage_bytes >= bytes) return WS_OK;
@@ -291,6 +320,7 @@ ws_status upload_positions(ws_handle *h, const float *pos_xyz)
 void free_all(ws_handle *h)
 {
     if (h->stream) hipStreamSynchronize(h->stream);
+    unpin_destination(h);
     drain_profile(h);
     for (auto e : h->pool) hipEventDestroy(e);
     free_grid(h);
@@ -610,6 +640,7 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
     if (st) return st;
     wsk_gather_positions(h->stream, h->cur.pos, (float *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
+    pin_destination(h, out_xyz, bytes);
     HIP_TRY(h, hipMemcpyAsync(out_xyz, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_profile(h);

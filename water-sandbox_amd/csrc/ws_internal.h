@@ -84,6 +84,8 @@ struct ws_handle {
     // staging for uploads / readback
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    void *pinned_dst = nullptr, *last_dst = nullptr;  // host destination of ws_read_positions we page-locked / saw last
+    size_t pinned_bytes = 0, last_dst_bytes = 0;
 
     // reference-layout sort view (lazy)
     uint32_t *v_keys = nullptr, *v_perm = nullptr, *v_tmp = nullptr, *v_count = nullptr,
