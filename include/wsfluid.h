@@ -99,6 +99,13 @@ typedef struct ws_device_cfg {
 
 #define WS_FLAG_NONE 0u
 #define WS_FLAG_PROFILE 1u /* record HIP events around every kernel of ws_step */
+/* Validation mode: execute the reference's six passes literally on the GPU -- N-bucket hashed table,
+ * the bitonic network stage by stage on the persisted permutation (src/fluid_compute.rs:256-271,
+ * assets/bitonic_sort.wgsl:22-46), atomicMin cell offsets, bucket walks in OFFSET_TABLE order -- with
+ * the same IEEE arithmetic.  It reproduces the reference's summation order, so it is comparable with
+ * a bit-faithful CPU restatement on every float and on particle_indicies itself.  Slow (S dispatches
+ * per step); single GPU only; never the benchmarked path. */
+#define WS_FLAG_REFERENCE_ORDER 2u
 
 typedef struct ws_handle ws_handle;
 

@@ -20,6 +20,7 @@ thread_local std::string g_create_error;
 
 void slab_free(ws_handle *h);          // ws_slab.inc
 ws_status slab_step(ws_handle *h);     // ws_slab.inc
+ws_status ref_upload_positions(ws_handle *h, const float *pos_xyz);
 
 ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
 {
@@ -289,6 +290,29 @@ void drain_profile(ws_handle *h)
     h->pending.clear();
 }
 
+// reference-order mode: (re)load the by-id arrays from 80-byte records
+ws_status ref_load(ws_handle *h, const ws_particle80 *host, bool reset_index)
+{
+    const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
+    ws_status st = ensure_stage(h, bytes);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->stage, host, bytes, hipMemcpyHostToDevice, h->stream));
+    wsk_ref_load(h->stream, (const ws_particle80 *)h->stage, h->ref, h->n, reset_index);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->steps = 0;
+    return WS_OK;
+}
+
+ws_status ref_upload_positions(ws_handle *h, const float *pos_xyz)
+{
+    std::vector<ws_particle80> rec(h->n);  // FluidParticle::make_vec_from_positions, fluid_compute.rs:118-130
+    memset(rec.data(), 0, rec.size() * sizeof(ws_particle80));
+    for (uint32_t i = 0; i < h->n; i++)
+        for (int c = 0; c < 3; c++) rec[i].position[c] = rec[i].predicted_position[c] = pos_xyz[3 * (size_t)i + c];
+    return ref_load(h, rec.data(), true);
+}
+
 // Put freshly uploaded `cur` into the "binned" state every ws_step starts from.
 ws_status bin_current(ws_handle *h)
 {
@@ -330,6 +354,8 @@ void free_all(ws_handle *h)
     hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->accept_mask); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
+    hipFree(h->ref.pos); hipFree(h->ref.vel); hipFree(h->ref.pred); hipFree(h->ref.acc); hipFree(h->ref.dens);
+    hipFree(h->ref.perm); hipFree(h->ref.keys); hipFree(h->ref.offs);
     slab_free(h);
     if (h->done) hipEventDestroy(h->done);
     if (h->stream && h->own_stream) hipStreamDestroy(h->stream);
@@ -492,6 +518,18 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
     CREATE_TRY(derive_dev(h, *params, n, &h->dev));
+    if (h->flags & WS_FLAG_REFERENCE_ORDER) {
+        h->refmode = true;
+        const size_t n16r = (size_t)n * 16;
+        CREATE_HIP(hipMalloc(&h->ref.pos, n16r)); CREATE_HIP(hipMalloc(&h->ref.vel, n16r));
+        CREATE_HIP(hipMalloc(&h->ref.pred, n16r)); CREATE_HIP(hipMalloc(&h->ref.acc, n16r));
+        CREATE_HIP(hipMalloc(&h->ref.dens, (size_t)n * 8));
+        CREATE_HIP(hipMalloc(&h->ref.perm, (size_t)n * 4)); CREATE_HIP(hipMalloc(&h->ref.keys, (size_t)n * 4));
+        CREATE_HIP(hipMalloc(&h->ref.offs, (size_t)n * 4));
+        CREATE_TRY(ref_upload_positions(h, pos_xyz));
+        *out = h;
+        return WS_OK;
+    }
     // +16 entries: phase 1 trips read up to U-1 slots past a run's end (masked, but must be mapped)
     const size_t n16 = ((size_t)n + 16) * 16;
     CREATE_HIP(hipMalloc(&h->cur.pos, n16));
@@ -541,6 +579,14 @@ ws_status ws_step(ws_handle *h)
     if (!h) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_step(h);
+    if (h->refmode) {
+        wsk_ref_step(h->stream, h->dev, h->ref);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipEventRecord(h->done, h->stream));
+        h->done_recorded = true;
+        h->steps++;
+        return WS_OK;
+    }
     const WsDev &d = h->dev;
     hipStream_t s = h->stream;
     {
@@ -617,6 +663,7 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
         nd.base = od.base; nd.n = od.n; nd.hash_n = od.hash_n;
     }
     h->params = *params;
+    if (h->refmode) regrid = false;  // no cell grid in reference-order mode
     if (!regrid) {
         h->dev = nd;  // by-value kernel argument: picked up by the next ws_step
         return WS_OK;
@@ -635,6 +682,14 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
     if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->refmode) {
+        std::vector<ws_particle80> rec(h->n);
+        const ws_status s_ = ws_read_particles(h, rec.data());
+        if (s_) return s_;
+        for (uint32_t i = 0; i < h->n; i++)
+            for (int c = 0; c < 3; c++) out_xyz[3 * (size_t)i + c] = rec[i].position[c];
+        return WS_OK;
+    }
     const size_t bytes = (size_t)h->n * 12;
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
@@ -655,6 +710,13 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
+    if (h->refmode) {
+        wsk_ref_store(h->stream, h->dev, h->ref, (ws_particle80 *)h->stage, h->n);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return WS_OK;
+    }
     wsk_gather_particles(h->stream, h->dev, h->cur, h->srt, h->accel, h->steps > 0, (ws_particle80 *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -668,6 +730,7 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz)
     if (!h || !pos_xyz) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->refmode) return ref_upload_positions(h, pos_xyz);
     return upload_positions(h, pos_xyz);
 }
 
@@ -676,6 +739,7 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
     if (!h || !in) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->refmode) return ref_load(h, in, false);  // write_slice("particles") leaves the index buffers alone
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
@@ -699,6 +763,13 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t n = h->n;
     hipStream_t s = h->stream;
+    if (h->refmode) {  // the real buffers, permutation included
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (keys_by_id) HIP_TRY(h, hipMemcpy(keys_by_id, h->ref.keys, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (perm) HIP_TRY(h, hipMemcpy(perm, h->ref.perm, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (cell_offsets) HIP_TRY(h, hipMemcpy(cell_offsets, h->ref.offs, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return WS_OK;
+    }
     if (!h->v_keys) {
         HIP_TRY(h, hipMalloc(&h->v_keys, (size_t)n * 4));
         HIP_TRY(h, hipMalloc(&h->v_perm, (size_t)n * 4));

@@ -42,6 +42,15 @@ struct WsSoA {
     float4 *pred;  // xyz = predicted_position (sorted copy: w = density after K4)
 };
 
+// Reference-order mode (WS_FLAG_REFERENCE_ORDER): the reference's own buffer set, by particle id
+struct WsRef {
+    float4 *pos = nullptr, *vel = nullptr, *pred = nullptr, *acc = nullptr;  // w = 0
+    float2 *dens = nullptr;    // (density, near density)
+    uint32_t *perm = nullptr;  // particle_indicies
+    uint32_t *keys = nullptr;  // particle_cell_indicies (by particle id)
+    uint32_t *offs = nullptr;  // cell_offsets
+};
+
 struct WsEventPair {
     uint32_t kernel;
     hipEvent_t a, b;
@@ -96,6 +105,9 @@ struct ws_handle {
     std::vector<hipEvent_t> pool;
     double prof_ms[WS_K_COUNT] = {0};
     uint64_t prof_cnt[WS_K_COUNT] = {0};
+
+    bool refmode = false;  // WS_FLAG_REFERENCE_ORDER
+    WsRef ref;
 
     // slab (multi-GPU) state; slab == nullptr on a single-GPU handle
     struct WsSlab *slab = nullptr;
@@ -153,6 +165,10 @@ void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, cons
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
 void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
+// reference-order mode
+void wsk_ref_step(hipStream_t s, const WsDev &d, WsRef r);
+void wsk_ref_load(hipStream_t s, const ws_particle80 *in_dev, WsRef r, uint32_t n, bool reset_index);
+void wsk_ref_store(hipStream_t s, const WsDev &d, WsRef r, ws_particle80 *out_dev, uint32_t n);
 // slabs
 void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
                       uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR);

@@ -28,6 +28,7 @@ PARTICLE_DTYPE = np.dtype(
 assert PARTICLE_DTYPE.itemsize == 80
 
 WS_FLAG_PROFILE = 1
+WS_FLAG_REFERENCE_ORDER = 2
 KERNEL_IDS = {"cell_scan": 0, "cell_scatter": 1, "reorder": 2, "density": 3, "force_integrate_bin": 4, "bin": 5}
 
 # every symbol include/wsfluid.h declares (tests check the library exports all of them)
@@ -189,7 +190,7 @@ class FluidWorker:
     device buffers, `run()` enqueues one step, `ready()` polls, `read_vec("particles")`
     returns the 80-byte records in original-id order."""
 
-    def __init__(self, positions, params=None, device=0, profile=False):
+    def __init__(self, positions, params=None, device=0, profile=False, reference_order=False):
         self._L = load_library()
         self._h = C.c_void_p()
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -197,7 +198,7 @@ class FluidWorker:
         self.params = params if params is not None else default_params()
         cfg = WsDeviceCfg()
         cfg.device = device
-        cfg.flags = WS_FLAG_PROFILE if profile else 0
+        cfg.flags = (WS_FLAG_PROFILE if profile else 0) | (WS_FLAG_REFERENCE_ORDER if reference_order else 0)
         st = self._L.ws_create(C.byref(self.params), positions.ctypes.data, self.n, C.byref(cfg), C.byref(self._h))
         if st != 0:
             raise WsError(st, (self._L.ws_last_error(None) or b"").decode())
