@@ -128,6 +128,34 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     return v;
 }
 
+// Wave-level aggregation of `atomicAdd(&table[key], 1)`: consecutive lanes with the same key form a
+// run; the run's first lane adds the run length once and every member gets base + its offset in the run.
+// Particles are processed in (previous) cell order, so in a dense fluid runs are ~7 lanes long and the
+// atomic traffic on the per-cell counters drops accordingly.  Returns this lane's value of the counter
+// (what its own atomicAdd(.., 1) would have returned in SOME serialisation).  `active` lanes only.
+__device__ __forceinline__ uint32_t wave_run_atomic_inc(uint32_t *__restrict__ table, uint32_t key, bool active)
+{
+    // May be called from divergent code: lanes that are not executing simply do not appear in `act`
+    // (their shuffled key is never trusted: a lane whose predecessor is not in `act` starts a run).
+    const int lane = threadIdx.x & 63;
+    const unsigned long long act = __ballot(active);
+    const uint32_t prev = __shfl_up(key, 1, 64);
+    const bool prev_active = lane > 0 && ((act >> (lane - 1)) & 1ull);
+    const bool head = active && (!prev_active || key != prev);
+    const unsigned long long heads = __ballot(head);
+    if (!active) return 0u;
+    const unsigned long long upto = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int hl = 63 - __builtin_clzll(upto);                      // my run's head lane
+    const unsigned long long above = (hl == 63) ? 0ull : (~((2ull << hl) - 1ull));
+    // the run ends at the next head or at the first inactive lane above the head
+    const unsigned long long stop = (heads | ~act) & above;
+    const int end = stop ? __builtin_ctzll(stop) : 64;
+    uint32_t base = 0;
+    if (lane == hl) base = atomicAdd(&table[key], (uint32_t)(end - hl));
+    base = __shfl(base, hl, 64);
+    return base + (uint32_t)(lane - hl);
+}
+
 // exclusive prefix of `v` over the 256-thread block; *total = block sum
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total)
 {
@@ -245,8 +273,9 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict
                                                       uint32_t *__restrict__ id_tmp, uint32_t n)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = atomicAdd(&cursor[keys[i]], 1u);
+    const bool active = i < n;
+    const uint32_t slot = wave_run_atomic_inc(cursor, active ? keys[i] : 0u, active);
+    if (!active) return;
     slot_tmp[slot] = i;
     if (id_tmp) id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
 }
@@ -424,7 +453,7 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
     // next step's hash_particles (simulation.wgsl:130-141) on the dense grid
     const uint32_t nc = grid_cell(d, qx, qy, qz);
     cid_out[i] = nc;
-    atomicAdd(&count[nc], 1u);
+    wave_run_atomic_inc(count, nc, true);  // one atomic per run of lanes that moved into the same cell
 }
 
 // ---------------------------------------------------------------------------------
