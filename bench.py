@@ -83,6 +83,12 @@ def load_traffic(config, dist):
 
 def main():
     args = parse_args()
+    # Only the JSON line may appear on stdout: libraries underneath (RCCL prints a version banner, c10d
+    # warns) write to fd 1 as well, so fd 1 points at stderr for the whole run and the result goes to the
+    # saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -213,7 +219,7 @@ def main():
         if args.breakdown:
             for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]):
                 print("%-22s %9.3f ms" % (k, v), file=sys.stderr)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     worker.close()
     if distributed:
         dist.barrier()
