@@ -157,6 +157,11 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params);
  * label (src/fluid_compute.rs:478,:483-485): n*3 floats in ORIGINAL-ID order.
  * Waits for enqueued steps first. */
 ws_status ws_read_positions(ws_handle *h, float *out_xyz);
+/* Optional: page-lock a host buffer the caller owns and keeps alive -- typically the position buffer
+ * update() fills every frame -- so that ws_read_positions / ws_read_particles into it run at PCIe rate
+ * (no pageable staging).  The caller must ws_unpin_host_buffer it before freeing it. */
+ws_status ws_pin_host_buffer(ws_handle *h, void *ptr, uint64_t bytes);
+ws_status ws_unpin_host_buffer(ws_handle *h, void *ptr);
 /* The full read_vec view (src/fluid_compute.rs:478): n records of 80 bytes in
  * original-id order.  density/pressure/acceleration are the values the last step
  * computed (0 before the first step). */

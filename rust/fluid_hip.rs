@@ -60,6 +60,8 @@ extern "C" {
     fn ws_ready(h: *mut WsHandle, ready: *mut c_int) -> c_int;
     fn ws_set_params(h: *mut WsHandle, params: *const WsParams) -> c_int;
     fn ws_read_positions(h: *mut WsHandle, out_xyz: *mut f32) -> c_int;
+    fn ws_pin_host_buffer(h: *mut WsHandle, ptr: *mut std::ffi::c_void, bytes: u64) -> c_int;
+    fn ws_unpin_host_buffer(h: *mut WsHandle, ptr: *mut std::ffi::c_void) -> c_int;
     fn ws_reset(h: *mut WsHandle, pos_xyz: *const f32) -> c_int;
     fn ws_last_error(h: *mut WsHandle) -> *const c_char;
 }
@@ -84,7 +86,10 @@ unsafe impl Sync for HipFluidWorker {}
 
 impl Drop for HipFluidWorker {
     fn drop(&mut self) {
-        unsafe { ws_destroy(self.handle) };
+        unsafe {
+            ws_unpin_host_buffer(self.handle, self.positions.as_mut_ptr() as *mut _);
+            ws_destroy(self.handle)
+        };
     }
 }
 
@@ -125,6 +130,9 @@ impl Plugin for FluidComputePlugin {
         let mut handle: *mut WsHandle = std::ptr::null_mut();
         let st = unsafe { ws_create(&params, flat.as_ptr(), points.len() as u32, std::ptr::null(), &mut handle) };
         assert_eq!(st, 0, "ws_create failed: {:?}", unsafe { std::ffi::CStr::from_ptr(ws_last_error(std::ptr::null_mut())) });
+        // the readback buffer lives as long as the worker: page-lock it once (PCIe-rate ws_read_positions)
+        let mut flat = flat;
+        unsafe { ws_pin_host_buffer(handle, flat.as_mut_ptr() as *mut _, (flat.len() * 4) as u64) };
         app.insert_resource(HipFluidWorker { handle, positions: flat })
             // the reference's unmap_all (Prepare) has nothing to do here; run (Pass) enqueues one step
             .add_systems(PostUpdate, run_step.in_set(ShaderPhysicsSet::Pass));

@@ -155,21 +155,21 @@ def test_full_size_properties_c3(ws):
     w.close(); w2.close()
 
 
-def test_repeated_readback_into_one_buffer_gets_pinned_and_stays_correct(ws):
-    """update() reads into the same host buffer every frame; from the second call on the library
-    page-locks it (PCIe-rate copy).  The data must not change with the copy path, and switching to
-    another buffer must work too."""
+def test_readback_into_an_explicitly_pinned_buffer(ws):
+    """update() reads into the same host buffer every frame; the host may page-lock it (PCIe-rate copy).
+    The data must not depend on the copy path."""
     pos = ws.cube_fluid(32, 16, 16)
     w = ws.FluidWorker(pos, ws.make_params(container_size=(10.0, 6.0, 6.0)))
-    L = ws.load_library()
     buf = np.empty((pos.shape[0], 3), np.float32)
+    w.pin_host_buffer(buf)
+    try:
+        for step in range(4):
+            w.run()
+            w.read_positions_into(buf)
+            assert np.array_equal(buf, w.read_vec("particles")["position"][:, :3])
+    finally:
+        w.unpin_host_buffer(buf)
     other = np.empty_like(buf)
-    for step in range(4):
-        w.run()
-        assert L.ws_read_positions(w._h, buf.ctypes.data) == 0
-        want = w.read_vec("particles")["position"][:, :3]
-        assert np.array_equal(buf, want)
-    assert L.ws_read_positions(w._h, other.ctypes.data) == 0
+    w.read_positions_into(other)  # a pageable buffer still works
     assert np.array_equal(other, buf)
-    assert L.ws_read_positions(w._h, buf.ctypes.data) == 0
     w.close()

@@ -25,8 +25,7 @@ for cfg, steps in (("c3", 30), ("c4", 10), ("c5", 5)):
         import ctypes as C
         buf = np.empty((n, 3), np.float32)  # the host's persistent position buffer, as in the Bevy update()
         L = ws.load_library()
-        for k in range(3):
-            L.ws_read_positions(w._h, buf.ctypes.data)
+        w.pin_host_buffer(buf)
         t4 = time.time()
         for _ in range(20):
             L.ws_read_positions(w._h, buf.ctypes.data); w.run()
@@ -34,4 +33,5 @@ for cfg, steps in (("c3", 30), ("c4", 10), ("c5", 5)):
         print("   c3 with ws_read_positions into one persistent buffer every step: %.2f ms/frame" % ((time.time() - t4) / 20 * 1e3), flush=True)
         t5 = time.time(); L.ws_read_positions(w._h, buf.ctypes.data); print("   one pinned readback: %.2f ms" % ((time.time()-t5)*1e3))
         assert np.array_equal(buf, w.read_positions())
+        w.unpin_host_buffer(buf)
     w.close()

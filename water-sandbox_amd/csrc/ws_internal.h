@@ -51,6 +51,11 @@ struct WsRef {
     uint32_t *offs = nullptr;  // cell_offsets
 };
 
+// planar copy of the sorted predicted positions (K4's radius tests)
+struct WsXYZ {
+    float *x = nullptr, *y = nullptr, *z = nullptr;
+};
+
 struct WsEventPair {
     uint32_t kernel;
     hipEvent_t a, b;
@@ -71,6 +76,7 @@ struct ws_handle {
 
     WsSoA cur{};   // state in the order of the last step (written by the force kernel)
     WsSoA srt{};   // cell-sorted copy the density/force kernels read
+    WsXYZ sxyz;                   // planar predicted positions in `srt` order
     uint32_t *cid_cur = nullptr;  // cell id per particle of `cur`
     uint32_t *cid_srt = nullptr;  // cell id per particle of `srt`
     int variant = WS_VARIANT_LISTED;  // density / near density ride in srt.pred[i].w / srt.vel[i].w
@@ -93,8 +99,6 @@ struct ws_handle {
     // staging for uploads / readback
     void *stage = nullptr;
     size_t stage_bytes = 0;
-    void *pinned_dst = nullptr, *last_dst = nullptr;  // host destination of ws_read_positions we page-locked / saw last
-    size_t pinned_bytes = 0, last_dst_bytes = 0;
 
     // reference-layout sort view (lazy)
     uint32_t *v_keys = nullptr, *v_perm = nullptr, *v_tmp = nullptr, *v_count = nullptr,
@@ -146,10 +150,11 @@ uint32_t wsk_scan_blocks(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
                  uint32_t *id_tmp, uint32_t n);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt);
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt, WsXYZ sxyz);
+void wsk_unpack_xyz(hipStream_t s, const float4 *pred, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
                  const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats, uint32_t *mask,
-                 uint32_t mask_stride);
+                 uint32_t mask_stride, WsXYZ sxyz);
 uint32_t wsk_mask_words(void);
 uint32_t wsk_tile_list_words(uint32_t n);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,

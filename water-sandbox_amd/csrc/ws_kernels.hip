@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
                                                       const uint32_t *__restrict__ id_tmp,
                                                       const uint32_t *__restrict__ cid_cur,
                                                       const uint32_t *__restrict__ start, WsSoA cur, WsSoA srt,
-                                                      uint32_t *__restrict__ cid_srt)
+                                                      uint32_t *__restrict__ cid_srt, WsXYZ sxyz)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (k >= d.n) return;
@@ -305,17 +305,42 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     uint32_t rank = 0;
     for (uint32_t t = b; t < e; t++) rank += (id_tmp[t] < id) ? 1u : 0u;
     const uint32_t dst = b + rank;
+    const float4 q = cur.pred[i];
     srt.pos[dst] = cur.pos[i];
     srt.vel[dst] = cur.vel[i];
-    srt.pred[dst] = cur.pred[i];
+    srt.pred[dst] = q;
+    // K4's radius tests read the predicted positions as three planar arrays: one 16-B load there
+    // fetches x (or y, z) of FOUR consecutive candidates
+    sxyz.x[dst] = q.x;
+    sxyz.y[dst] = q.y;
+    sxyz.z[dst] = q.z;
     cid_srt[dst] = c;
 }
 
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt)
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt, WsXYZ sxyz)
 {
     hipLaunchKernelGGL(k_reorder, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur, start,
-                       cur, srt, cid_srt);
+                       cur, srt, cid_srt, sxyz);
+}
+
+// slabs: planar copy of the ghost layers' predicted positions after halo A ([lo0, hi0) and [lo1, hi1))
+__global__ void __launch_bounds__(WS_BLOCK) k_unpack_xyz(const float4 *__restrict__ pred, WsXYZ sxyz, uint32_t lo0,
+                                                         uint32_t n0, uint32_t lo1, uint32_t n1)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (t >= n0 + n1) return;
+    const uint32_t i = t < n0 ? lo0 + t : lo1 + (t - n0);
+    const float4 q = pred[i];
+    sxyz.x[i] = q.x;
+    sxyz.y[i] = q.y;
+    sxyz.z[i] = q.z;
+}
+
+void wsk_unpack_xyz(hipStream_t s, const float4 *pred, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1)
+{
+    if (n0 + n1 == 0) return;
+    hipLaunchKernelGGL(k_unpack_xyz, dim3(cdiv(n0 + n1, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pred, sxyz, lo0, n0, lo1, n1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -660,10 +685,44 @@ __device__ __forceinline__ void nd_run(const WsDev &d, const NdRuns &R, uint32_t
     phase2(cnt);
 }
 
+typedef float nd_f4 __attribute__((ext_vector_type(4)));
+typedef float nd_f4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive floats, 4-byte aligned
+
+// K4's phase 1 over one run on the planar arrays: 4 candidates per trip from three 16-B loads, the
+// squared distances as packed f32 vector arithmetic (same IEEE operations per candidate, same order).
+template <int K, class Push, class Phase2, class Note>
+__device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t j, uint32_t e, uint32_t &cnt,
+                                              WsXYZ p, Push &&push, Phase2 &&phase2, Note &&note)
+{
+    for (;;) {
+        while (j < e && cnt < (uint32_t)K) {
+            const nd_f4 X = *reinterpret_cast<const nd_f4u *>(p.x + j);
+            const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(p.y + j);
+            const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(p.z + j);
+            __builtin_amdgcn_sched_barrier(0);  // the three loads are issued before any is consumed
+            const nd_f4 ex = X - o.x, ey = Y - o.y, ez = Z - o.z;
+            const nd_f4 d2 = ex * ex + ey * ey + ez * ez;
+            uint32_t bits = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool acc = (j + u < e) && !(d2[u] > d.d2_accept);
+                push(cnt, j + u, d2[u]);  // branch-free: store always, advance the slot on accept
+                cnt += acc ? 1u : 0u;
+                bits |= (acc ? 1u : 0u) << u;
+            }
+            note(min(4u, e - j), bits);
+            j += 4;
+        }
+        if (!__ballot(cnt >= (uint32_t)K && j < e)) break;  // nobody is blocked on a full list
+        phase2(cnt);
+        cnt = 0;
+    }
+}
+
 template <int U>
 __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ tile_list,
                                                          const uint32_t *__restrict__ start,
-                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt, WsXYZ sxyz,
                                                          uint32_t *__restrict__ accept_mask, uint32_t mask_stride,
                                                          uint32_t *__restrict__ stats)
 {
@@ -707,8 +766,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
             r.b2 = start[cc + rowz - 1];
             r.e2 = start[cc + rowz + 2];
         }
-        nb_plane_phase1<ND_K, U>(
-            d, o, r, false, i, cnt, [&](uint32_t a) { return srt.pred[a]; }, push, phase2, note);
+        nd_run_planar<ND_K>(d, o, r.b0, r.e0, cnt, sxyz, push, phase2, note);
+        nd_run_planar<ND_K>(d, o, r.b1, r.e1, cnt, sxyz, push, phase2, note);
+        nd_run_planar<ND_K>(d, o, r.b2, r.e2, cnt, sxyz, push, phase2, note);
     }
     phase2(cnt);
     if (valid) {
@@ -1056,14 +1116,11 @@ static int nd_unroll()
 }
 
 static void launch_density_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
-                                  const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, uint32_t *mask,
+                                  const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsXYZ sxyz, uint32_t *mask,
                                   uint32_t mask_stride, uint32_t *stats)
 {
-    switch (nd_unroll()) {
-        case 2: hipLaunchKernelGGL(k_density_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, mask, mask_stride, stats); break;
-        case 8: hipLaunchKernelGGL(k_density_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, mask, mask_stride, stats); break;
-        default: hipLaunchKernelGGL(k_density_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, mask, mask_stride, stats); break;
-    }
+    hipLaunchKernelGGL(k_density_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, sxyz, mask,
+                       mask_stride, stats);
 }
 
 static void launch_force_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
@@ -1083,7 +1140,7 @@ uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
 
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
                  const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats, uint32_t *mask,
-                 uint32_t mask_stride)
+                 uint32_t mask_stride, WsXYZ sxyz)
 {
     if (alias || variant == WS_VARIANT_SIMPLE) {
         if (alias)
@@ -1098,9 +1155,9 @@ void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uin
         hipMemsetAsync(tile_list, 0, 4, s);
         hipLaunchKernelGGL(k_density_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
                            cid_srt, srt, tile_list);
-        launch_density_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, mask, mask_stride, stats);
+        launch_density_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, sxyz, mask, mask_stride, stats);
     } else {
-        launch_density_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, mask, mask_stride, stats);
+        launch_density_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, sxyz, mask, mask_stride, stats);
     }
 }
 
