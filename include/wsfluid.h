@@ -106,6 +106,10 @@ typedef struct ws_device_cfg {
  * a bit-faithful CPU restatement on every float and on particle_indicies itself.  Slow (S dispatches
  * per step); single GPU only; never the benchmarked path. */
 #define WS_FLAG_REFERENCE_ORDER 2u
+/* Pair terms of K4/K5 with correctly rounded sqrt and division (the CPU oracle's arithmetic) instead of the
+ * default hardware v_sqrt_f32 / v_rcp_f32 forms (1 ULP each; x / y evaluated as x * rcp(y)), which stay inside the
+ * accuracy WGSL grants the reference's own GPU execution (x / y: 2.5 ULP).  ~2x slower density/force kernels. */
+#define WS_FLAG_IEEE_DIVISION 4u
 
 typedef struct ws_handle ws_handle;
 
@@ -254,8 +258,8 @@ ws_status ws_profile_reset(ws_handle *h);
 /* Restrict WS_FLAG_PROFILE's events to the kernel ids whose bit is set in mask (default: all),
  * so that a timed region carries two events per step instead of two per kernel. */
 ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
-/* Cumulative device-side counters: out[0] / out[1] = density / force workgroup tiles whose
- * candidate ranges overflowed LDS and took the direct-from-global path; the rest reserved. */
+/* Cumulative device-side counters: out[0] = particle-steps with more candidates than the accept mask holds
+ * (their waves took the full sweep in the force kernel); the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding). */
 ws_status ws_grid_dims(ws_handle *h, uint32_t dims[3]);

@@ -20,9 +20,14 @@ def _check_sort_view(O, orc, worker):
     assert np.array_equal(off, orc.cell_offsets)
 
 
-def _teacher_forced(O, ws, pos, params, steps, label):
+BOTH_ARITHMETICS = pytest.mark.parametrize("ieee", [False, True], ids=["hw-rcp-sqrt", "ieee-division"])
+
+
+def _teacher_forced(O, ws, pos, params, steps, label, ieee=False):
+    """ieee: WS_FLAG_IEEE_DIVISION (the oracle's correctly rounded sqrt / division in the pair terms) instead of the
+    default 1-ULP hardware forms.  The tolerance is the same for both."""
     orc = oracle_from_params(O, pos, params)
-    worker = ws.FluidWorker(pos, params)
+    worker = ws.FluidWorker(pos, params, ieee_division=ieee)
     state = orc.particles.copy()
     for s in range(steps):
         want = oracle_one_step(O, orc, state)
@@ -42,24 +47,28 @@ def _teacher_forced(O, ws, pos, params, steps, label):
     worker.close()
 
 
-def test_lattice_4096_cube(oracle, ws):
+@BOTH_ARITHMETICS
+def test_lattice_4096_cube(oracle, ws, ieee):
     pos = ws.cube_fluid(16, 16, 16)
-    _teacher_forced(oracle, ws, pos, ws.default_params(), 6, "cube16")
+    _teacher_forced(oracle, ws, pos, ws.default_params(), 6, "cube16", ieee)
 
 
-def test_planar_c1_lattice(oracle, ws):
+@BOTH_ARITHMETICS
+def test_planar_c1_lattice(oracle, ws, ieee):
     pos, params = ws.workloads.make_workload("c1", "lattice")
-    _teacher_forced(oracle, ws, pos, params, 4, "c1-lattice")
+    _teacher_forced(oracle, ws, pos, params, 4, "c1-lattice", ieee)
 
 
-def test_planar_c1_cloud(oracle, ws):
+@BOTH_ARITHMETICS
+def test_planar_c1_cloud(oracle, ws, ieee):
     pos, params = ws.workloads.make_workload("c1", "cloud")
-    _teacher_forced(oracle, ws, pos, params, 4, "c1-cloud")
+    _teacher_forced(oracle, ws, pos, params, 4, "c1-cloud", ieee)
 
 
-def test_reference_default_65536(oracle, ws):
+@BOTH_ARITHMETICS
+def test_reference_default_65536(oracle, ws, ieee):
     pos, params = ws.workloads.make_workload("ref", "lattice")
-    _teacher_forced(oracle, ws, pos, params, 3, "ref-65536")
+    _teacher_forced(oracle, ws, pos, params, 3, "ref-65536", ieee)
 
 
 def test_free_running_matches_first_steps(oracle, ws):
@@ -78,13 +87,13 @@ def test_free_running_matches_first_steps(oracle, ws):
     worker.close()
 
 
-def _run_variant(ws, variant, pos, params, steps):
+def _run_variant(ws, variant, pos, params, steps, ieee=False):
     import os
 
     old = os.environ.get("WS_VARIANT")
     os.environ["WS_VARIANT"] = variant
     try:
-        w = ws.FluidWorker(pos, params)
+        w = ws.FluidWorker(pos, params, ieee_division=ieee)
     finally:
         if old is None:
             os.environ.pop("WS_VARIANT", None)
@@ -96,14 +105,28 @@ def _run_variant(ws, variant, pos, params, steps):
     return out
 
 
+@BOTH_ARITHMETICS
 @pytest.mark.parametrize("name,dist,steps", [("c2", "cloud", 12), ("c2", "lattice", 6), ("c1", "cloud", 8), ("c2", "cloud", 150)])
-def test_tiled_kernels_equal_simple_kernels_bitwise(ws, name, dist, steps):
-    """The LDS-tiled (+ listed for dense tiles) and the all-listed density/force kernels visit neighbours in the same order with the same IEEE
-    operations as the one-thread-per-particle kernels: every field must be bit-identical, also
-    after several free-running steps (any divergence would be amplified, not hidden)."""
+def test_listed_kernels_equal_simple_kernels_bitwise(ws, name, dist, steps, ieee):
+    """The listed density/force kernels (planar radius sweep, LDS compaction, neighbour lists) visit neighbours in
+    the same order with the same operations as the one-thread-per-particle kernels: every field must be
+    bit-identical, also after many free-running steps (any divergence would be amplified, not hidden) -- with
+    either arithmetic."""
     pos, params = ws.workloads.make_workload(name, dist)
-    a = _run_variant(ws, "simple", pos, params, steps)
-    for variant in ("tiled", "listed"):
-        b = _run_variant(ws, variant, pos, params, steps)
-        for f in a.dtype.names:
-            assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), (variant, f)
+    a = _run_variant(ws, "simple", pos, params, steps, ieee)
+    b = _run_variant(ws, "listed", pos, params, steps, ieee)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f
+
+
+def test_the_two_arithmetics_differ_only_in_the_last_bits(ws):
+    """Hardware rcp/sqrt against correctly rounded division after ONE step from the same state: relative
+    difference of the accelerations at the level of a few ULP of their magnitude, positions almost always equal."""
+    pos, params = ws.workloads.make_workload("c2", "cloud")
+    a = _run_variant(ws, "listed", pos, params, 1, False)
+    b = _run_variant(ws, "listed", pos, params, 1, True)
+    assert np.array_equal(a["density"][:, 0].view(np.uint32) != b["density"][:, 0].view(np.uint32),
+                          a["density"][:, 0] != b["density"][:, 0])
+    scale = float(np.max(np.abs(b["acceleration"])))
+    assert float(np.max(np.abs(a["acceleration"] - b["acceleration"]))) <= 64 * np.finfo(np.float32).eps * scale
+    assert float(np.max(np.abs(a["density"] - b["density"]))) <= 16 * np.finfo(np.float32).eps * float(np.max(b["density"]))

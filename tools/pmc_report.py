@@ -2,7 +2,7 @@
 """Summarise tools/pmc.sh output: per-kernel counter averages over the LAST `steps` dispatches."""
 import collections, csv, glob, sys
 tag = sys.argv[1]; last = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-for part in "abc":
+for part in "abcd":
     files = glob.glob("gpurun_out/pmc_%s_%s/*/*_counter_collection.csv" % (tag, part))
     if not files: continue
     rows = list(csv.DictReader(open(files[0])))

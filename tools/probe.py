@@ -22,6 +22,6 @@ w.profile_reset()
 w.run(steps)
 w.sync()
 prof = {k: round(v[0] / max(v[1], 1), 4) for k, v in w.profile().items() if v[1]}
-print(json.dumps({"variant": os.environ.get("WS_VARIANT", "tiled"), "config": cfg, "dist": dist, "warmup": warm,
+print(json.dumps({"variant": os.environ.get("WS_VARIANT", "listed"), "config": cfg, "dist": dist, "warmup": warm,
                   "steps": steps, "ms": prof, "total_ms": round(sum(prof.values()), 4), "stats": w.stats()}))
 w.close()

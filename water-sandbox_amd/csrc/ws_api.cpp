@@ -203,6 +203,13 @@ ws_status upload_mult(ws_handle *h)
     return WS_OK;
 }
 
+// kernel family and pair arithmetic of a new handle (flags already set)
+void configure_kernels(ws_handle *h)
+{
+    if (const char *v = getenv("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : WS_VARIANT_LISTED;
+    h->ieee = (h->flags & WS_FLAG_IEEE_DIVISION) != 0;
+}
+
 ws_status ensure_stage(ws_handle *h, size_t bytes)
 {
     if (h->stage_bytes >= bytes) return WS_OK;
@@ -280,13 +287,12 @@ void enqueue_step(ws_handle *h)
     }
     {
         Prof p(h, WS_K_DENSITY);
-        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->tile_list, h->stats, h->accept_mask,
-                    h->mask_stride, h->sxyz);
+        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->ieee, h->stats, h->mask, h->sxyz);
     }
     {
         Prof p(h, WS_K_FORCE);
         wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->tile_list, h->accept_mask, h->mask_stride);
+                  h->variant, h->ieee, h->mask);
     }
 }
 
@@ -351,7 +357,7 @@ void free_all(ws_handle *h)
     hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
     hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->accept_mask); hipFree(h->tile_list); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
+    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->mask.words); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
     hipFree(h->ref.pos); hipFree(h->ref.vel); hipFree(h->ref.pred); hipFree(h->ref.acc); hipFree(h->ref.dens);
@@ -494,7 +500,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     h->flags = cfg ? cfg->flags : 0;
     h->n = n;
     h->params = *params;
-    if (const char *v = getenv("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : strcmp(v, "tiled") == 0 ? WS_VARIANT_TILED : WS_VARIANT_LISTED;
+    configure_kernels(h);
 
     auto bail = [&](ws_status s) {
         g_create_error = h->err;
@@ -545,10 +551,10 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->id_tmp, (size_t)n * 4));
-    h->mask_stride = n;
-    CREATE_HIP(hipMalloc(&h->accept_mask, (size_t)wsk_mask_words() * h->mask_stride * 4));
-    CREATE_HIP(hipMalloc(&h->tile_list, (size_t)wsk_tile_list_words(n) * 4));
-    CREATE_HIP(hipMemset(h->tile_list, 0, 4));
+    if (h->variant == WS_VARIANT_LISTED) {
+        h->mask.stride = n;
+        CREATE_HIP(hipMalloc(&h->mask.words, (size_t)wsk_mask_words() * n * 4));
+    }
     CREATE_HIP(hipMalloc(&h->stats, 64));
     CREATE_HIP(hipMemset(h->stats, 0, 64));
     CREATE_TRY(alloc_grid(h));

@@ -32,8 +32,15 @@ struct WsDev {
     uint32_t hash_n;  // the reference's `num_particles` in hash_cell (global N)
 };
 
-// density / force kernel family (WS_VARIANT=simple|tiled in the environment, for A/B tests)
-enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_TILED = 1, WS_VARIANT_LISTED = 2 };
+// density / force kernel family (WS_VARIANT=simple in the environment, for A/B tests)
+enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_LISTED = 2 };
+
+// Accept masks K4 writes and K5 walks: bit s of owned particle p (sorted order, p = index - base) = its s-th
+// candidate in visit order is a neighbour.  words[w][p]: a wave's access to one word row is one coalesced segment.
+struct WsMask {
+    uint32_t *words;
+    uint32_t stride;  // particles per row
+};
 
 // SoA particle set (one of two ping-pong copies).
 struct WsSoA {
@@ -88,10 +95,9 @@ struct ws_handle {
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
     uint32_t *bsum = nullptr;     // scan block sums
     uint32_t nscan_blocks = 0;
-    uint32_t *accept_mask = nullptr;  // [ND_MASK_WORDS][mask_stride]: K4's accept bits per candidate, read by K5
-    uint32_t mask_stride = 0;
-    uint32_t *tile_list = nullptr; // [0] = tiles handed to the listed kernels this step, [1..] = their ids
-    uint32_t *stats = nullptr;    // device counters: [0]/[1] density/force tiles that overflowed LDS
+    WsMask mask = {nullptr, 0};   // accept masks (listed variant)
+    bool ieee = false;            // WS_FLAG_IEEE_DIVISION: correctly rounded sqrt / division in the pair terms
+    uint32_t *stats = nullptr;    // device counters: [0] particle-steps with more candidates than the mask holds
     uint8_t *mult = nullptr;      // 27 stencil multiplicities (hash aliasing), device
     bool alias = false;
     size_t grid_alloc_cells = 0;
@@ -153,13 +159,11 @@ void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const 
                  const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt, WsXYZ sxyz);
 void wsk_unpack_xyz(hipStream_t s, const float4 *pred, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats, uint32_t *mask,
-                 uint32_t mask_stride, WsXYZ sxyz);
+                 const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz);
 uint32_t wsk_mask_words(void);
-uint32_t wsk_tile_list_words(uint32_t n);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
-               float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant,
-               const uint32_t *tile_list, const uint32_t *mask, uint32_t mask_stride);
+               float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
+               WsMask mask);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
                           ws_particle80 *out, uint32_t n);

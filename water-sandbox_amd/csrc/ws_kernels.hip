@@ -384,11 +384,32 @@ __device__ __forceinline__ uint32_t alias_mult(const WsDev &d, const uint8_t *__
 // per-pair arithmetic of K4 / K5, shared by every kernel variant.
 // ---------------------------------------------------------------------------------
 
+// sqrt and division of the pair terms.  IEEE = true: correctly rounded, the arithmetic of a CPU restatement (and
+// always of the reference-order validation mode).  IEEE = false (default of the production kernels): the
+// hardware's v_sqrt_f32 / v_rcp_f32 (1 ULP each), i.e. x / y evaluated as x * rcp(y) -- within the accuracy
+// the reference's shading language itself grants its GPU (WGSL: x / y 2.5 ULP, sqrt as 1 / inverseSqrt at
+// 2 ULP), written in the same operation order.  ~9 correctly rounded divisions and a square root cost ~110 of
+// the ~180 instructions of one force pair.
+template <bool IEEE>
+__device__ __forceinline__ float ws_sqrt(float x)
+{
+    if constexpr (IEEE) return sqrtf(x);
+    else return __builtin_amdgcn_sqrtf(x);
+}
+
+template <bool IEEE>
+struct WsDivisor {
+    float v;
+    __device__ __forceinline__ explicit WsDivisor(float den) : v(IEEE ? den : __builtin_amdgcn_rcpf(den)) {}
+    __device__ __forceinline__ float operator()(float num) const { return IEEE ? num / v : num * v; }
+};
+
 // simulation.wgsl:176-183; d2 has already passed the radius test
+template <bool IEEE>
 __device__ __forceinline__ void density_pair(const WsDev &d, float d2, float &density, float &near_density,
                                              uint32_t mult)
 {
-    const float dst = sqrtf(d2);
+    const float dst = ws_sqrt<IEEE>(d2);
     const float w = sk_density(d, dst), wn = sk_near(d, dst);
     for (uint32_t r = 0; r < mult; r++) {
         density += w;
@@ -403,15 +424,17 @@ struct ForceAcc {
 // simulation.wgsl:238-263.  (ex,ey,ez) = neighbour.pred - own.pred, d2 its squared length.
 // nrho_x / nrho_y = the neighbour's density / near density; its pressures are recomputed
 // from them (simulation.wgsl:192-193: the same two IEEE operations K4 would have stored).
+template <bool IEEE>
 __device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, float ez, float d2, float nrho_x,
                                            float nrho_y, float4 nvel, float4 vel, float pressure, float near_pressure,
                                            ForceAcc &a, uint32_t mult)
 {
-    const float dst = sqrtf(d2);
+    const float dst = ws_sqrt<IEEE>(d2);
+    const WsDivisor<IEEE> by_dst(dst), by_rho(nrho_x), by_near_rho(nrho_y);
     if (dst > 0.f) {
-        ex = ex / dst;
-        ey = ey / dst;
-        ez = ez / dst;
+        ex = by_dst(ex);
+        ey = by_dst(ey);
+        ez = by_dst(ez);
     } else {
         ex = 0.f;
         ey = 1.f;
@@ -423,9 +446,9 @@ __device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, f
     const float shared = (pressure + npress) / 2.f;
     const float slope_near = sk_der_near(d, dst);
     const float shared_near = (near_pressure + nnear) / 2.f;
-    const float ax = ex * shared * slope / nrho_x, ay = ey * shared * slope / nrho_x, az = ez * shared * slope / nrho_x;
-    const float bx = ex * shared_near * slope_near / nrho_y, by = ey * shared_near * slope_near / nrho_y,
-                bz = ez * shared_near * slope_near / nrho_y;
+    const float ax = by_rho(ex * shared * slope), ay = by_rho(ey * shared * slope), az = by_rho(ez * shared * slope);
+    const float bx = by_near_rho(ex * shared_near * slope_near), by = by_near_rho(ey * shared_near * slope_near),
+                bz = by_near_rho(ez * shared_near * slope_near);
     const float visc = sk_visc(d, dst);
     const float wx = (nvel.x - vel.x) * visc, wy = (nvel.y - vel.y) * visc, wz = (nvel.z - vel.z) * visc;
     for (uint32_t r = 0; r < mult; r++) {
@@ -483,20 +506,16 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
 
 // ---------------------------------------------------------------------------------
 // variant "simple": one lane per particle, one candidate per loop trip, pair arithmetic
-// inline.  The reference-shaped baseline of the A/B tests, and the path used when the
-// reference's hashed table would alias inside one stencil (tiny N: multiplicity table).
+// inline.  The reference-shaped baseline of the A/B tests, the path used when the
+// reference's hashed table would alias inside one stencil (tiny N: multiplicity table),
+// and the fallback of the listed K5 for particles whose neighbour list overflowed.
 // ---------------------------------------------------------------------------------
-template <bool ALIAS>
-__global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint32_t *__restrict__ start,
-                                                             const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                             const uint8_t *__restrict__ mult)
+template <bool ALIAS, bool IEEE>
+__device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSoA srt,
+                                                     const uint8_t *__restrict__ mult, float4 o, int c, float &density,
+                                                     float &near_density)
 {
-    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.base + d.n) return;
-    const float4 o = srt.pred[i];
-    const int c = (int)cid_srt[i];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    float density = 0.f, near_density = 0.f;
     for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
@@ -506,28 +525,18 @@ __global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint
                 const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
                 const float d2 = ex * ex + ey * ey + ez * ez;
                 if (d2 > d.d2_accept) continue;
-                density_pair(d, d2, density, near_density, ALIAS ? alias_mult(d, mult, o, q) : 1u);
+                density_pair<IEEE>(d, d2, density, near_density, ALIAS ? alias_mult(d, mult, o, q) : 1u);
             }
         }
     }
-    density_store(density, near_density, i, srt);
 }
 
-template <bool ALIAS>
-__global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32_t *__restrict__ start,
-                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
-                                                           float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                           uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
+template <bool ALIAS, bool IEEE>
+__device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSoA srt,
+                                                   const uint8_t *__restrict__ mult, uint32_t i, float4 o, float4 vel, int c,
+                                                   float pressure, float near_pressure, ForceAcc &acc)
 {
-    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.base + d.n) return;
-    const float4 o = srt.pred[i];    // w = own density
-    const float4 vel = srt.vel[i];   // w = own near density
-    const float pressure = d.pressure_scalar * (o.w - d.target_density);
-    const float near_pressure = d.near_pressure_scalar * vel.w;
-    const int c = (int)cid_srt[i];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
@@ -539,163 +548,87 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
                 const float d2 = ex * ex + ey * ey + ez * ez;
                 if (d2 > d.d2_accept) continue;
                 const float4 nvel = srt.vel[j];
-                force_pair(d, ex, ey, ez, d2, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
-                           ALIAS ? alias_mult(d, mult, o, q) : 1u);
+                force_pair<IEEE>(d, ex, ey, ez, d2, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
+                                 ALIAS ? alias_mult(d, mult, o, q) : 1u);
             }
         }
     }
+}
+
+template <bool ALIAS, bool IEEE>
+__global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint32_t *__restrict__ start,
+                                                             const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                             const uint8_t *__restrict__ mult)
+{
+    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.base + d.n) return;
+    float density = 0.f, near_density = 0.f;
+    density_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, srt.pred[i], (int)cid_srt[i], density, near_density);
+    density_store(density, near_density, i, srt);
+}
+
+template <bool ALIAS, bool IEEE>
+__global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32_t *__restrict__ start,
+                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
+                                                           float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                                           uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
+{
+    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.base + d.n) return;
+    const float4 o = srt.pred[i];    // w = own density
+    const float4 vel = srt.vel[i];   // w = own near density
+    const float pressure = d.pressure_scalar * (o.w - d.target_density);
+    const float near_pressure = d.near_pressure_scalar * vel.w;
+    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    force_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, i, o, vel, (int)cid_srt[i], pressure, near_pressure, acc);
     force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
 // ---------------------------------------------------------------------------------
-// Two-phase neighbour sweep, the core of the MI355X kernels.
+// variant "listed" (default): the MI355X kernels.
 //
 // The cell grid is z-fastest, so the 27 cells a particle searches are 9 contiguous particle
 // runs (one per (dx,dy) column, three z-cells each) instead of 27 hashed bucket walks.
-// Phase 1 walks each run with a plain counted loop -- U candidates per trip, their loads issued
-// together and differing only by an immediate offset -- doing ONLY the radius test; every
-// accepted candidate is pushed onto a per-lane list in LDS ([slot][lane] layout,
-// conflict-free; the store is unconditional, only the slot advance depends on the test).  Phase 2 then runs the expensive pair arithmetic (sqrt, the IEEE divides)
-// over the compacted list, i.e. on the ~15 % of candidates that pass, instead of dragging
-// it through every trip at ~15 % lane utilisation.  A list is flushed through phase 2 when
-// some lane of the wave is blocked on a full one, so any neighbour count works.
-// Visit order = (dx, dy, z, slot) ascending in every variant: all of them produce the same
-// sums bit for bit.
-//   fetch(a)            candidate a's {pred.xyz, density}
-//   push(slot, a, d2)   record an accepted candidate in list slot `slot`
-//   phase2(cnt)         consume the lane's list (cnt entries, in visit order)
+// One lane per particle; consecutive lanes are consecutive particles of the cell-sorted
+// order, i.e. they sit in the same or neighbouring cells, so their candidate loads are the same
+// or adjacent addresses and L1 serves them as broadcasts.
+//
+// K4 (density) makes the ONE pass over the candidates (~6x more of them than neighbours):
+//   phase 1  radius test only, 4 candidates per trip from the planar x/y/z arrays; every accepted
+//            candidate's d2 is pushed onto a per-lane list in LDS ([slot][lane]: conflict-free;
+//            the store is unconditional, only the slot advance depends on the test), and ONE BIT
+//            PER CANDIDATE in visit order goes to the particle's accept mask
+//            (mask[word][particle]: coalesced, candidates / 8 bytes per particle);
+//   phase 2  when some lane of the wave is blocked on a full list, every lane consumes its list:
+//            the density terms (sqrt + kernel polynomials) on the accepted candidates only.
+// K5 (force) accepts exactly the same candidates (same positions, same threshold; it only drops the
+// particle itself) in the same order, so it does no radius tests: each lane iterates over the set
+// bits of its mask, maps the bit number to the neighbour's index through a 9-entry per-lane run table
+// in LDS, gathers {pred, density} and {vel, near density} (2 x 16 B, issued one neighbour ahead) and
+// does the pair arithmetic -- then integrates and bins for the next step.
+// A particle with more than 32 * ND_MASK_WORDS candidates keeps no mask; a wave that holds such a
+// particle takes the simple sweep in K5 instead (same visit order, same operations).
+// Visit order = (dx, dy, z, slot) ascending in every variant: all of them produce the same sums
+// bit for bit.
 // ---------------------------------------------------------------------------------
-struct NbRange3 {
-    uint32_t b0, e0, b1, e1, b2, e2;  // the three runs [b, e) of the plane, in visit order
-};
-
-struct NbNoNote {  // note(nvalid, bits): a trip tested `nvalid` candidates; bit u of `bits` = candidate u accepted
-    __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
-};
-
-template <int K, int U, class Fetch, class Push, class Phase2, class Note>
-__device__ __forceinline__ void nb_run_phase1(const WsDev &d, float4 o, uint32_t j, uint32_t e, bool skip_self,
-                                              uint32_t self_a, uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2,
-                                              Note &&note)
-{
-    // One contiguous run [j, e): candidate addresses are j, j+1, ... (the loads of a trip differ
-    // only by an immediate offset).  Lanes past their run's end keep loading in-bounds slots
-    // (every candidate array is padded by U entries) and are masked out of the accept test.
-    for (;;) {
-        while (j < e && cnt < (uint32_t)K) {
-            float4 q[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) q[u] = fetch(j + u);
-            __builtin_amdgcn_sched_barrier(0);  // all U loads are issued before any is consumed
-            uint32_t bits = 0;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const float ex = q[u].x - o.x, ey = q[u].y - o.y, ez = q[u].z - o.z;
-                const float d2 = ex * ex + ey * ey + ez * ez;
-                // branch-free push: always store at the current slot, advance it only on accept
-                const bool acc = (j + u < e) && !(d2 > d.d2_accept) && !(skip_self && j + u == self_a);
-                push(cnt, j + u, d2);
-                cnt += acc ? 1u : 0u;
-                bits |= (acc ? 1u : 0u) << u;
-            }
-            note(min((uint32_t)U, e - j), bits);
-            j += U;
-        }
-        if (!__ballot(cnt >= (uint32_t)K && j < e)) break;  // nobody is blocked on a full list
-        phase2(cnt);
-        cnt = 0;
-    }
-}
-
-template <int K, int U, class Fetch, class Push, class Phase2, class Note = NbNoNote>
-__device__ __forceinline__ void nb_plane_phase1(const WsDev &d, float4 o, NbRange3 r, bool skip_self, uint32_t self_a,
-                                                uint32_t &cnt, Fetch &&fetch, Push &&push, Phase2 &&phase2,
-                                                Note &&note = NbNoNote())
-{
-    nb_run_phase1<K, U>(d, o, r.b0, r.e0, false, self_a, cnt, fetch, push, phase2, note);
-    nb_run_phase1<K, U>(d, o, r.b1, r.e1, skip_self, self_a, cnt, fetch, push, phase2, note);  // own cell: middle run
-    nb_run_phase1<K, U>(d, o, r.b2, r.e2, false, self_a, cnt, fetch, push, phase2, note);
-}
-
-// ---------------------------------------------------------------------------------
-// variant "listed" (default): one lane per particle, candidates straight from global memory.
-// Consecutive lanes are consecutive particles of the cell-sorted order, i.e. they sit in the
-// same or neighbouring cells: their candidate loads are the same or adjacent addresses, L1
-// serves them as broadcasts, and with no staging and no barriers the kernels run at full
-// occupancy.  (Measured against the LDS-staged variant below on C3: 10-25 % faster in the
-// sparse AND the dense regime -- DESIGN.md "Kernel variants".)  LDS holds only the per-lane
-// compacted lists.  If tile_list != nullptr only the NB_P-particle tiles it names are done.
-// ---------------------------------------------------------------------------------
-#define NB_P 512           // particles per tile of the "tiled" variant (and of tile lists)
 #define ND_P 256           // threads per workgroup
 #define ND_K 16            // list fill level that triggers a flush
-#define ND_ROWS(U) (ND_K + (U) - 1)
-
-__device__ __forceinline__ bool nd_particle(const WsDev &d, const uint32_t *__restrict__ tile_list, uint32_t &i)
-{
-    if (tile_list) {
-        const uint32_t entry = blockIdx.x / (NB_P / ND_P);
-        if (entry >= tile_list[0]) return false;
-        i = d.base + tile_list[1u + entry] * NB_P + (blockIdx.x % (NB_P / ND_P)) * ND_P + threadIdx.x;
-    } else {
-        i = d.base + blockIdx.x * ND_P + threadIdx.x;
-    }
-    return true;
-}
-
-// K4 and K5 accept exactly the same candidates (same positions, same threshold; K5 only drops the
-// particle itself), and they enumerate them in the same order.  So K4 records, per particle, ONE BIT
-// PER CANDIDATE in visit order (accept_mask[word][particle], coalesced), and K5 replaces its whole
-// radius-test phase by a walk over the set bits: ~18 instructions per candidate become ~8 per ACCEPTED
-// candidate, for (candidates / 8) bytes of mask traffic.  Particles with more than 32 * ND_MASK_WORDS
-// candidates (none in the benchmark states) do the full test again in K5.
-#define ND_MASK_WORDS 32
-
-struct NdRuns {
-    uint32_t b[9], e[9];
-    uint32_t total;
-};
-
-__device__ __forceinline__ NdRuns nd_runs(const WsDev &d, const uint32_t *__restrict__ start, int c, bool valid)
-{
-    const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    NdRuns r;
-    r.total = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int cc = d.guard + c + (k / 3 - 1) * rowy + (k % 3 - 1) * rowz;
-        r.b[k] = valid ? start[cc - 1] : 0u;
-        r.e[k] = valid ? start[cc + 2] : 0u;
-        r.total += r.e[k] - r.b[k];
-    }
-    return r;
-}
-
-template <int U, bool SKIP_SELF, class Push, class Phase2, class Note>
-__device__ __forceinline__ void nd_run(const WsDev &d, const NdRuns &R, uint32_t i, float4 o,
-                                       const float4 *__restrict__ pred, Push &&push, Phase2 &&phase2, Note &&note)
-{
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
-        const NbRange3 r = {R.b[3 * p], R.e[3 * p], R.b[3 * p + 1], R.e[3 * p + 1], R.b[3 * p + 2], R.e[3 * p + 2]};
-        nb_plane_phase1<ND_K, U>(
-            d, o, r, SKIP_SELF && p == 1, i, cnt, [&](uint32_t a) { return pred[a]; }, push, phase2, note);
-    }
-    phase2(cnt);
-}
+#define ND_ROWS (ND_K + 3) // a trip of 4 candidates may start at fill level K-1
+#define ND_MASK_WORDS 64   // 2048 candidates per particle (256 B of mask rows each; only the words in use are touched)
 
 typedef float nd_f4 __attribute__((ext_vector_type(4)));
 typedef float nd_f4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive floats, 4-byte aligned
 
 // K4's phase 1 over one run on the planar arrays: 4 candidates per trip from three 16-B loads, the
 // squared distances as packed f32 vector arithmetic (same IEEE operations per candidate, same order).
-template <int K, class Push, class Phase2, class Note>
+// Lanes past their run's end keep loading in-bounds slots (the planes are padded) and are masked
+// out of the accept test.  note(nvalid, bits): the trip tested nvalid candidates, bit u = candidate u accepted.
+template <class Push, class Phase2, class Note>
 __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t j, uint32_t e, uint32_t &cnt,
                                               WsXYZ p, Push &&push, Phase2 &&phase2, Note &&note)
 {
     for (;;) {
-        while (j < e && cnt < (uint32_t)K) {
+        while (j < e && cnt < (uint32_t)ND_K) {
             const nd_f4 X = *reinterpret_cast<const nd_f4u *>(p.x + j);
             const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(p.y + j);
             const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(p.z + j);
@@ -706,88 +639,84 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const bool acc = (j + u < e) && !(d2[u] > d.d2_accept);
-                push(cnt, j + u, d2[u]);  // branch-free: store always, advance the slot on accept
+                push(cnt, d2[u]);  // branch-free: store always, advance the slot on accept
                 cnt += acc ? 1u : 0u;
                 bits |= (acc ? 1u : 0u) << u;
             }
             note(min(4u, e - j), bits);
             j += 4;
         }
-        if (!__ballot(cnt >= (uint32_t)K && j < e)) break;  // nobody is blocked on a full list
+        if (!__ballot(cnt >= (uint32_t)ND_K && j < e)) break;  // nobody is blocked on a full list
         phase2(cnt);
         cnt = 0;
     }
 }
 
-template <int U>
-__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ tile_list,
-                                                         const uint32_t *__restrict__ start,
+template <bool IEEE>
+__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ start,
                                                          const uint32_t *__restrict__ cid_srt, WsSoA srt, WsXYZ sxyz,
-                                                         uint32_t *__restrict__ accept_mask, uint32_t mask_stride,
-                                                         uint32_t *__restrict__ stats)
+                                                         WsMask mask, uint32_t *__restrict__ stats)
 {
-    __shared__ float list[ND_ROWS(U) * ND_P];  // K4's phase 2 needs only d2: the list holds it
-    if (tile_list && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], tile_list[0]);
-    uint32_t i;
-    if (!nd_particle(d, tile_list, i)) return;
+    __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
+    const uint32_t i = d.base + blockIdx.x * ND_P + threadIdx.x;
     const bool valid = i < d.base + d.n;
     const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const float4 o = srt.pred[iv];
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
     float density = 0.f, near_density = 0.f;
-    // accept mask of this particle: bit `seq` = candidate number seq in visit order.  Trips append up to
-    // U bits to a 64-bit accumulator; a full low word goes out (coalesced across lanes: [word][particle]).
+    // accept mask: bit `seq` = candidate number seq in visit order.  Trips append up to 4 bits to a 64-bit
+    // accumulator; a full low word goes out (coalesced across lanes).
     unsigned long long acc64 = 0;
     uint32_t seq = 0;
-    uint32_t *mrow = accept_mask + iv;
-    auto push = [&](uint32_t slot, uint32_t, float d2) { list[slot * ND_P + threadIdx.x] = d2; };
+    uint32_t *mrow = mask.words + (iv - d.base);
+    auto push = [&](uint32_t slot, float d2) { list[slot * ND_P + threadIdx.x] = d2; };
     auto phase2 = [&](uint32_t cnt) {
-        for (uint32_t k = 0; k < cnt; k++) density_pair(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
+        for (uint32_t k = 0; k < cnt; k++) density_pair<IEEE>(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
     };
     auto note = [&](uint32_t nvalid, uint32_t bits) {
         acc64 |= (unsigned long long)bits << (seq & 31u);
         const uint32_t w0 = seq >> 5;
         seq += nvalid;
         if ((seq >> 5) != w0) {
-            if (w0 < ND_MASK_WORDS) mrow[(size_t)w0 * mask_stride] = (uint32_t)acc64;
+            if (w0 < ND_MASK_WORDS) mrow[(size_t)w0 * mask.stride] = (uint32_t)acc64;
             acc64 >>= 32;
         }
     };
     uint32_t cnt = 0;
     for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
         const int cc = d.guard + c + (p - 1) * rowy;
-        NbRange3 r = {0, 0, 0, 0, 0, 0};
+        uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0, b2 = 0, e2 = 0;
         if (valid) {
-            r.b0 = start[cc - rowz - 1];
-            r.e0 = start[cc - rowz + 2];
-            r.b1 = start[cc - 1];
-            r.e1 = start[cc + 2];
-            r.b2 = start[cc + rowz - 1];
-            r.e2 = start[cc + rowz + 2];
+            b0 = start[cc - rowz - 1];
+            e0 = start[cc - rowz + 2];
+            b1 = start[cc - 1];
+            e1 = start[cc + 2];
+            b2 = start[cc + rowz - 1];
+            e2 = start[cc + rowz + 2];
         }
-        nd_run_planar<ND_K>(d, o, r.b0, r.e0, cnt, sxyz, push, phase2, note);
-        nd_run_planar<ND_K>(d, o, r.b1, r.e1, cnt, sxyz, push, phase2, note);
-        nd_run_planar<ND_K>(d, o, r.b2, r.e2, cnt, sxyz, push, phase2, note);
+        nd_run_planar(d, o, b0, e0, cnt, sxyz, push, phase2, note);
+        nd_run_planar(d, o, b1, e1, cnt, sxyz, push, phase2, note);
+        nd_run_planar(d, o, b2, e2, cnt, sxyz, push, phase2, note);
     }
     phase2(cnt);
     if (valid) {
-        if ((seq & 31u) && (seq >> 5) < ND_MASK_WORDS) mrow[(size_t)(seq >> 5) * mask_stride] = (uint32_t)acc64;
+        if ((seq & 31u) && (seq >> 5) < ND_MASK_WORDS) mrow[(size_t)(seq >> 5) * mask.stride] = (uint32_t)acc64;
+        if (seq > 32u * ND_MASK_WORDS) atomicAdd(&stats[0], 1u);  // rare by construction: one counter is enough
         density_store(density, near_density, i, srt);
     }
 }
 
-template <int U>
-__global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *__restrict__ tile_list,
-                                                       const uint32_t *__restrict__ start,
+template <bool IEEE>
+__global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                       uint32_t *__restrict__ count,
-                                                       const uint32_t *__restrict__ accept_mask, uint32_t mask_stride)
+                                                       uint32_t *__restrict__ count, WsMask mask)
 {
-    __shared__ uint32_t list[ND_ROWS(U) * ND_P];  // global indices of the accepted neighbours
-    uint32_t i;
-    if (!nd_particle(d, tile_list, i)) return;
+    // per-lane run table: candidate numbers [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
+    __shared__ uint32_t t_end[10 * ND_P];  // row 9: a sentinel no candidate number reaches
+    __shared__ uint32_t t_delta[9 * ND_P];
+    const uint32_t i = d.base + blockIdx.x * ND_P + threadIdx.x;
     const bool valid = i < d.base + d.n;
     const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const float4 o = srt.pred[iv];   // w = own density
@@ -795,393 +724,115 @@ __global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
     const float near_pressure = d.near_pressure_scalar * vel.w;
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto phase2 = [&](uint32_t cnt) {
-        // two 16-B gathers per accepted neighbour ({pred, density}, {vel, near density}),
-        // issued one list entry ahead of the arithmetic that consumes them
-        float4 q_next = o, nvel_next = vel;
-        if (cnt > 0) {
-            const uint32_t j = list[threadIdx.x];
-            q_next = srt.pred[j];
-            nvel_next = srt.vel[j];
-        }
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float4 q = q_next, nvel = nvel_next;
-            if (k + 1 < cnt) {
-                const uint32_t j = list[(k + 1) * ND_P + threadIdx.x];
-                q_next = srt.pred[j];
-                nvel_next = srt.vel[j];
-            }
-            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-            force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
-                       1u);
-        }
-    };
-    auto push = [&](uint32_t slot, uint32_t a, float) { list[slot * ND_P + threadIdx.x] = a; };
-    const NdRuns R = nd_runs(d, start, (int)cid_srt[iv], valid);
-    // wave-uniform choice: if every lane's candidates fit the mask, walk K4's accept bits; else test again
-    if (!__ballot(R.total > 32u * ND_MASK_WORDS)) {
-        const uint32_t *mrow = accept_mask + iv;
-        uint32_t cnt = 0, seq0 = 0;
+    const int c = (int)cid_srt[iv];
+    uint32_t total = 0;
+    {
+        const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
 #pragma unroll
         for (int r = 0; r < 9; r++) {
-            const uint32_t b = R.b[r], end = seq0 + (R.e[r] - b);
-            uint32_t s = seq0, word = 0, jbase = 0;  // word: accepted bits still pending in the current chunk
+            const int cc = d.guard + c + (r / 3 - 1) * rowy + (r % 3 - 1) * rowz;
+            const uint32_t b = valid ? start[cc - 1] : 0u, e = valid ? start[cc + 2] : 0u;
+            t_delta[r * ND_P + threadIdx.x] = b - total;
+            total += e - b;
+            t_end[r * ND_P + threadIdx.x] = total;
+        }
+        t_end[9 * ND_P + threadIdx.x] = 0xFFFFFFFFu;
+    }
+    if (!__ballot(total > 32u * ND_MASK_WORDS)) {
+        const uint32_t *mrow = mask.words + (iv - d.base);
+        const uint32_t nwords = (total + 31u) >> 5;
+        // iterator over the set bits of the mask = the neighbours in visit order
+        uint32_t word = 0, wbase = 0, widx = 0, run = 0;
+        uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
+        uint32_t end_r = t_end[threadIdx.x], delta_r = t_delta[threadIdx.x];
+        auto next = [&](uint32_t &j) -> bool {
             for (;;) {
-                while (cnt < (uint32_t)ND_K) {
-                    if (word == 0) {
-                        if (s >= end) break;
-                        const uint32_t off = s & 31u, nb = min(32u - off, end - s);
-                        word = mrow[(size_t)(s >> 5) * mask_stride] >> off;
-                        if (nb < 32u) word &= (1u << nb) - 1u;
-                        jbase = b + (s - seq0);
-                        s += nb;
-                        continue;
-                    }
-                    const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
-                    word &= word - 1u;
-                    const uint32_t j = jbase + bit;
-                    if (j != i) {  // `particle_index == neighbour_index`, simulation.wgsl:232
-                        push(cnt, j, 0.f);
-                        cnt++;
-                    }
+                while (word == 0u) {
+                    if (widx >= nwords) return false;
+                    word = wnext;
+                    wbase = widx << 5;
+                    widx++;
+                    wnext = widx < nwords ? mrow[(size_t)widx * mask.stride] : 0u;
                 }
-                if (!__ballot(cnt >= (uint32_t)ND_K && (word != 0u || s < end))) break;
-                phase2(cnt);
-                cnt = 0;
+                const uint32_t s = wbase + (uint32_t)__ffs((int)word) - 1u;
+                word &= word - 1u;
+                while (s >= end_r) {
+                    run++;
+                    end_r = t_end[run * ND_P + threadIdx.x];
+                    delta_r = t_delta[min(run, 8u) * ND_P + threadIdx.x];
+                }
+                j = s + delta_r;
+                if (j != i) return true;  // `particle_index == neighbour_index`, simulation.wgsl:232
             }
-            seq0 = end;
+        };
+        // Software pipeline: while neighbour k computes, the records of neighbour k+1 are in flight and the
+        // iterator has already produced k+2.  Exhausted lanes load their own record (always a valid address).
+        uint32_t j1 = iv, j2 = iv;
+        bool have0 = next(j1);
+        float4 q_next = srt.pred[have0 ? j1 : iv], nvel_next = srt.vel[have0 ? j1 : iv];
+        bool have1 = have0 && next(j2);
+        while (have0) {
+            const float4 q = q_next, nvel = nvel_next;
+            q_next = srt.pred[have1 ? j2 : iv];
+            nvel_next = srt.vel[have1 ? j2 : iv];
+            have0 = have1;
+            have1 = have1 && next(j2);
+            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
+            force_pair<IEEE>(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure,
+                             acc, 1u);
         }
-        phase2(cnt);
-    } else {
-        nd_run<U, true>(d, R, i, o, srt.pred, push, phase2, NbNoNote());
+    } else if (valid) {
+        force_sweep_simple<false, IEEE>(d, start, srt, nullptr, i, o, vel, c, pressure, near_pressure, acc);
     }
     if (valid) force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
-// ---------------------------------------------------------------------------------
-// variant "tiled": the LDS-staged form, kept selectable (WS_VARIANT=tiled) for A/B runs.
-//
-// A workgroup owns NB_P consecutive particles of the sorted order; their cells span
-// [c_lo, c_hi].  For one (dx,dy) column offset the candidates of ALL of them are one
-// contiguous particle range [start[c_lo + s - 1], start[c_hi + s + 2]) ("column" range), and
-// for one dx plane the three column ranges lie inside one contiguous "merged" range
-// [start[c_lo + dx*ny*nz - nz - 1], start[c_hi + dx*ny*nz + nz + 2]), which is smaller than the
-// three together when the tile spans several z-rows (sparse fluid).  Per plane the workgroup
-// stages whichever is smaller into LDS (coalesced 16-B loads); phase 1 then reads candidates
-// with ds_read_b128.  Tiles whose three planes do not fit in LDS at once (dense rows) are
-// appended to a tile list and done by the listed kernels.
-// ---------------------------------------------------------------------------------
-#define NB_K 16            // neighbour-list fill level that triggers a flush
-#define NB_U 2
-#define NB_ROWS (NB_K + NB_U - 1)
-#define NB_CAP 3968        // staged candidates per workgroup (float4 each)
-#define NB_ALIGN 32        // each staged range starts on a multiple of this
-#define NB_TAB (NB_CAP / NB_ALIGN)
-#define NB_LDS_BYTES (NB_CAP * 16 + NB_ROWS * NB_P * 2 + NB_TAB * 4)  // 81 392 B: 2 workgroups / CU
-
-struct NbTile {
-    float4 *sm;       // [NB_CAP] staged {pred.xyz, density}
-    uint16_t *list;   // [NB_ROWS][NB_P]
-    int32_t *tab;     // [NB_TAB] (global index - LDS index) of the range covering each 32-slot group
-};
-
-__device__ __forceinline__ NbTile nb_carve(char *smem)
-{
-    NbTile t;
-    t.sm = reinterpret_cast<float4 *>(smem);
-    t.list = reinterpret_cast<uint16_t *>(smem + NB_CAP * 16);
-    t.tab = reinterpret_cast<int32_t *>(smem + NB_CAP * 16 + NB_ROWS * NB_P * 2);
-    return t;
-}
-
-// XCD-aware workgroup -> tile map: workgroups are dealt round-robin over the 8 XCDs, so
-// giving XCD x the x-th contiguous eighth of the tiles keeps each XCD's L2 on one x-slab
-// of the sorted particles (plus its halo planes) instead of all of them.  Speed only.
-__device__ __forceinline__ uint32_t nb_tile_index(uint32_t ntiles)
-{
-    const uint32_t per = (ntiles + 7u) >> 3;
-    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-}
-
-__device__ __forceinline__ uint32_t nb_align(uint32_t x) { return (x + (NB_ALIGN - 1)) & ~(uint32_t)(NB_ALIGN - 1); }
-
-// workgroup-uniform geometry of a tile (everything here lives in SGPRs)
-struct NbGeo {
-    int c_lo, c_hi, rowz, rowy, guard;
-};
-
-__device__ __forceinline__ void nb_merged(const NbGeo &g, const uint32_t *__restrict__ start, int p, uint32_t &g0,
-                                          uint32_t &len)
-{
-    const int s = (p - 1) * g.rowy;
-    g0 = start[g.guard + g.c_lo + s - g.rowz - 1];
-    len = start[g.guard + g.c_hi + s + g.rowz + 2] - g0;
-}
-
-__device__ __forceinline__ void nb_column(const NbGeo &g, const uint32_t *__restrict__ start, int p, int dy, uint32_t &g0,
-                                          uint32_t &len)
-{
-    const int s = (p - 1) * g.rowy + dy * g.rowz;
-    g0 = start[g.guard + g.c_lo + s - 1];
-    len = start[g.guard + g.c_hi + s + 2] - g0;
-}
-
-// LDS slots plane p needs, and whether the merged form is the smaller one
-__device__ __forceinline__ uint32_t nb_plane_cost(const NbGeo &g, const uint32_t *__restrict__ start, int p, bool &merged)
-{
-    uint32_t g0, len, cm, cs = 0;
-    nb_merged(g, start, p, g0, len);
-    cm = nb_align(len);
-#pragma unroll
-    for (int dy = -1; dy <= 1; dy++) {
-        nb_column(g, start, p, dy, g0, len);
-        cs += nb_align(len);
-    }
-    merged = cm <= cs;
-    return merged ? cm : cs;
-}
-
-// Stage plane p at LDS slot `used` (advanced) and return this lane's three runs in it
-// (LDS indices).  No barrier here.
-__device__ __forceinline__ NbRange3 nb_stage_plane(const NbTile &t, const NbGeo &g, int p, bool merged, uint32_t &used,
-                                                   const uint32_t *__restrict__ start, uint32_t i, bool valid, int c,
-                                                   const float4 *__restrict__ pred, uint32_t &self_l)
-{
-    uint32_t sg0[3], sl0[3];  // per column: first global particle / first LDS slot of its range
-    auto stage_range = [&](uint32_t g0, uint32_t len, uint32_t l0) {
-        for (uint32_t k = threadIdx.x; k < len; k += NB_P) t.sm[l0 + k] = pred[g0 + k];
-        const uint32_t groups = nb_align(len) / NB_ALIGN;
-        if (threadIdx.x < groups) t.tab[l0 / NB_ALIGN + threadIdx.x] = (int32_t)(g0 - l0);
-    };
-    if (merged) {
-        uint32_t g0, len;
-        nb_merged(g, start, p, g0, len);
-        sg0[0] = sg0[1] = sg0[2] = g0;
-        sl0[0] = sl0[1] = sl0[2] = used;
-        stage_range(g0, len, used);
-        used += nb_align(len);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            uint32_t len;
-            nb_column(g, start, p, k - 1, sg0[k], len);
-            sl0[k] = used;
-            stage_range(sg0[k], len, used);
-            used += nb_align(len);
-        }
-    }
-    uint32_t b[3] = {0, 0, 0}, e[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int s = (p - 1) * g.rowy + (k - 1) * g.rowz;
-        if (valid) {
-            b[k] = start[g.guard + c + s - 1] - sg0[k] + sl0[k];
-            e[k] = start[g.guard + c + s + 2] - sg0[k] + sl0[k];
-        }
-    }
-    if (p == 1) self_l = i - sg0[1] + sl0[1];  // column (dx,dy) = (0,0) holds the lane's own cell
-    const NbRange3 r = {b[0], e[0], b[1], e[1], b[2], e[2]};
-    return r;
-}
-
-// Returns false (workgroup-uniform, before touching LDS) when the tile's candidates do not fit
-// in LDS at once; such tiles go to the listed kernels.
-template <bool SKIP_SELF, class Phase2>
-__device__ __forceinline__ bool nb_tile_run(const WsDev &d, const NbTile &t, const uint32_t *__restrict__ start,
-                                            const uint32_t *__restrict__ cid_srt, uint32_t i0, uint32_t i, bool valid,
-                                            int c, float4 o, const float4 *__restrict__ pred, Phase2 &&phase2)
-{
-    NbGeo g;
-    g.c_lo = (int)cid_srt[i0];  // workgroup-uniform: scalar loads
-    g.c_hi = (int)cid_srt[min(i0 + NB_P, d.base + d.n) - 1u];
-    g.rowz = d.dim[2];
-    g.rowy = d.dim[1] * d.dim[2];
-    g.guard = d.guard;
-    bool m0, m1, m2;
-    const uint32_t c0 = nb_plane_cost(g, start, 0, m0), c1 = nb_plane_cost(g, start, 1, m1),
-                   c2 = nb_plane_cost(g, start, 2, m2);
-    if (c0 + c1 + c2 > NB_CAP) return false;
-    uint32_t self_l = 0, used = 0;
-    const NbRange3 R0 = nb_stage_plane(t, g, 0, m0, used, start, i, valid, c, pred, self_l);
-    const NbRange3 R1 = nb_stage_plane(t, g, 1, m1, used, start, i, valid, c, pred, self_l);
-    const NbRange3 R2 = nb_stage_plane(t, g, 2, m2, used, start, i, valid, c, pred, self_l);
-    __syncthreads();
-    uint32_t cnt = 0;
-    for (int p = 0; p < 3; p++) {  // workgroup-uniform loop: dx = -1, 0, +1 keeps the visit order
-        const NbRange3 r = (p == 0) ? R0 : (p == 1) ? R1 : R2;
-        nb_plane_phase1<NB_K, NB_U>(
-            d, o, r, SKIP_SELF && p == 1, self_l, cnt, [&](uint32_t a) { return t.sm[a]; },
-            [&](uint32_t slot, uint32_t a, float) { t.list[slot * NB_P + threadIdx.x] = (uint16_t)a; }, phase2);
-    }
-    phase2(cnt);
-    return true;
-}
-
-__global__ void __launch_bounds__(NB_P, 4) k_density_tiled(WsDev d, uint32_t ntiles, const uint32_t *__restrict__ start,
-                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt,
-                                                           uint32_t *__restrict__ tile_list)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t tile = nb_tile_index(ntiles);
-    if (tile >= ntiles) return;
-    const NbTile t = nb_carve(smem);
-    const uint32_t i0 = d.base + tile * NB_P, i = i0 + threadIdx.x;
-    const bool valid = i < d.base + d.n;
-    const uint32_t iv = valid ? i : d.base + d.n - 1u;
-    const int c = (int)cid_srt[iv];
-    const float4 o = srt.pred[iv];
-    float density = 0.f, near_density = 0.f;
-    const bool done = nb_tile_run<false>(d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, [&](uint32_t cnt) {
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float4 q = t.sm[t.list[k * NB_P + threadIdx.x]];
-            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-            density_pair(d, ex * ex + ey * ey + ez * ez, density, near_density, 1u);
-        }
-    });
-    if (!done) {
-        // dense tile: hand it to the listed kernels (this step's K4 and K5); tile_list[0] = count
-        if (threadIdx.x == 0) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile;
-        return;
-    }
-    if (valid) density_store(density, near_density, i, srt);
-}
-
-__global__ void __launch_bounds__(NB_P, 4) k_force_tiled(WsDev d, uint32_t ntiles, const uint32_t *__restrict__ start,
-                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
-                                                         float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                         uint32_t *__restrict__ count)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t tile = nb_tile_index(ntiles);
-    if (tile >= ntiles) return;
-    const NbTile t = nb_carve(smem);
-    const uint32_t i0 = d.base + tile * NB_P, i = i0 + threadIdx.x;
-    const bool valid = i < d.base + d.n;
-    const uint32_t iv = valid ? i : d.base + d.n - 1u;
-    const int c = (int)cid_srt[iv];
-    const float4 o = srt.pred[iv];   // w = own density
-    const float4 vel = srt.vel[iv];  // w = own near density
-    const float pressure = d.pressure_scalar * (o.w - d.target_density);
-    const float near_pressure = d.near_pressure_scalar * vel.w;
-    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool done = nb_tile_run<true>(d, t, start, cid_srt, i0, i, valid, c, o, srt.pred, [&](uint32_t cnt) {
-        // the neighbour's velocity + near density is one 16-B gather by its global index,
-        // issued one list entry ahead of the arithmetic that consumes it
-        float4 nvel_next = vel;
-        uint32_t idx_next = 0;
-        if (cnt > 0) {
-            idx_next = t.list[threadIdx.x];
-            nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
-        }
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t idx = idx_next;
-            const float4 nvel = nvel_next;
-            if (k + 1 < cnt) {
-                idx_next = t.list[(k + 1) * NB_P + threadIdx.x];
-                nvel_next = srt.vel[(uint32_t)((int32_t)idx_next + t.tab[idx_next / NB_ALIGN])];
-            }
-            const float4 q = t.sm[idx];
-            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-            force_pair(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
-                       1u);
-        }
-    });
-    if (!done) return;  // in this step's tile list: k_force_listed does it
-    if (valid) force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
-}
-
-static bool g_tiled_attr_done = false;
-static void nb_set_attrs()
-{
-    if (g_tiled_attr_done) return;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_density_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        NB_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k_force_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        NB_LDS_BYTES);
-    g_tiled_attr_done = true;
-}
-
-uint32_t wsk_tile_list_words(uint32_t n) { return 1u + cdiv(n, NB_P); }
-
-// candidates per phase-1 trip of the listed kernels (WS_UNROLL=2|4|8 in the environment)
-static int nd_unroll()
-{
-    static int u = 0;
-    if (!u) {
-        const char *e = getenv("WS_UNROLL");
-        u = e ? atoi(e) : 4;
-        if (u != 2 && u != 4 && u != 8) u = 4;
-    }
-    return u;
-}
-
-static void launch_density_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
-                                  const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsXYZ sxyz, uint32_t *mask,
-                                  uint32_t mask_stride, uint32_t *stats)
-{
-    hipLaunchKernelGGL(k_density_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, sxyz, mask,
-                       mask_stride, stats);
-}
-
-static void launch_force_listed(hipStream_t s, uint32_t blocks, const WsDev &d, const uint32_t *tile_list,
-                                const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out, float4 *accel,
-                                uint32_t *cid_out, uint32_t *count, const uint32_t *mask, uint32_t mask_stride)
-{
-    switch (nd_unroll()) {
-        case 2: hipLaunchKernelGGL(k_force_listed<2>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride); break;
-        case 8: hipLaunchKernelGGL(k_force_listed<8>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride); break;
-        default: hipLaunchKernelGGL(k_force_listed<4>, dim3(blocks), dim3(ND_P), 0, s, d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride); break;
-    }
-}
-
-// tile_list (variant "tiled" only): [0] = number of tiles handed to the listed kernels this
-// step (zeroed here), [1..] = their indices
 uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
 
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
-                 const uint8_t *mult, bool alias, int variant, uint32_t *tile_list, uint32_t *stats, uint32_t *mask,
-                 uint32_t mask_stride, WsXYZ sxyz)
+template <bool IEEE>
+static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+                           const uint8_t *mult, bool alias, int variant, uint32_t *stats, WsMask mask, WsXYZ sxyz)
 {
-    if (alias || variant == WS_VARIANT_SIMPLE) {
-        if (alias)
-            hipLaunchKernelGGL(k_density_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                               cid_srt, srt, mult);
-        else
-            hipLaunchKernelGGL(k_density_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                               cid_srt, srt, mult);
-    } else if (variant == WS_VARIANT_TILED) {
-        nb_set_attrs();
-        const uint32_t ntiles = cdiv(d.n, NB_P);
-        hipMemsetAsync(tile_list, 0, 4, s);
-        hipLaunchKernelGGL(k_density_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
-                           cid_srt, srt, tile_list);
-        launch_density_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, sxyz, mask, mask_stride, stats);
-    } else {
-        launch_density_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, sxyz, mask, mask_stride, stats);
-    }
+    if (alias)
+        hipLaunchKernelGGL((k_density_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                           cid_srt, srt, mult);
+    else if (variant == WS_VARIANT_SIMPLE)
+        hipLaunchKernelGGL((k_density_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                           cid_srt, srt, mult);
+    else
+        hipLaunchKernelGGL((k_density_listed<IEEE>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), 0, s, d, start, cid_srt, srt, sxyz,
+                           mask, stats);
+}
+
+template <bool IEEE>
+static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+                         WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias,
+                         int variant, WsMask mask)
+{
+    if (alias)
+        hipLaunchKernelGGL((k_force_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
+                           srt, out, accel, cid_out, count, mult);
+    else if (variant == WS_VARIANT_SIMPLE)
+        hipLaunchKernelGGL((k_force_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                           cid_srt, srt, out, accel, cid_out, count, mult);
+    else
+        hipLaunchKernelGGL((k_force_listed<IEEE>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), 0, s, d, start, cid_srt, srt, out,
+                           accel, cid_out, count, mask);
+}
+
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+                 const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz)
+{
+    if (ieee) launch_density<true>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
+    else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
 }
 
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
-               float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant,
-               const uint32_t *tile_list, const uint32_t *mask, uint32_t mask_stride)
+               float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
+               WsMask mask)
 {
-    if (alias || variant == WS_VARIANT_SIMPLE) {
-        if (alias)
-            hipLaunchKernelGGL(k_force_simple<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
-                               srt, out, accel, cid_out, count, mult);
-        else
-            hipLaunchKernelGGL(k_force_simple<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                               cid_srt, srt, out, accel, cid_out, count, mult);
-    } else if (variant == WS_VARIANT_TILED) {
-        nb_set_attrs();
-        const uint32_t ntiles = cdiv(d.n, NB_P);
-        hipLaunchKernelGGL(k_force_tiled, dim3(8 * cdiv(ntiles, 8)), dim3(NB_P), NB_LDS_BYTES, s, d, ntiles, start,
-                           cid_srt, srt, out, accel, cid_out, count);
-        launch_force_listed(s, ntiles * (NB_P / ND_P), d, tile_list, start, cid_srt, srt, out, accel, cid_out, count, mask,
-                            mask_stride);
-    } else {
-        launch_force_listed(s, cdiv(d.n, ND_P), d, nullptr, start, cid_srt, srt, out, accel, cid_out, count, mask, mask_stride);
-    }
+    if (ieee) launch_force<true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+    else launch_force<false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1609,7 +1260,7 @@ __global__ void __launch_bounds__(WS_BLOCK) kr_density(WsDev d, WsRef r)
             const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
             const float d2 = ex * ex + ey * ey + ez * ez;
             if (d2 > d.d2_accept) continue;
-            density_pair(d, d2, density, near_density, 1u);
+            density_pair<true>(d, d2, density, near_density, 1u);
         }
     }
     r.dens[pid] = make_float2(density + 0.00001f, near_density + 0.00001f);
@@ -1640,7 +1291,7 @@ __global__ void __launch_bounds__(WS_BLOCK) kr_force(WsDev d, WsRef r)
             const float d2 = ex * ex + ey * ey + ez * ez;
             if (d2 > d.d2_accept) continue;
             const float2 nrho = r.dens[nb];
-            force_pair(d, ex, ey, ez, d2, nrho.x, nrho.y, r.vel[nb], vel, pressure, near_pressure, a, 1u);
+            force_pair<true>(d, ex, ey, ez, d2, nrho.x, nrho.y, r.vel[nb], vel, pressure, near_pressure, a, 1u);
         }
     }
     r.acc[pid] = make_float4(a.pfx / rho.x + a.vfx * d.viscosity, a.pfy / rho.x + a.vfy * d.viscosity,

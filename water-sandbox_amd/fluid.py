@@ -29,6 +29,7 @@ assert PARTICLE_DTYPE.itemsize == 80
 
 WS_FLAG_PROFILE = 1
 WS_FLAG_REFERENCE_ORDER = 2
+WS_FLAG_IEEE_DIVISION = 4
 KERNEL_IDS = {"cell_scan": 0, "cell_scatter": 1, "reorder": 2, "density": 3, "force_integrate_bin": 4, "bin": 5}
 
 # every symbol include/wsfluid.h declares (tests check the library exports all of them)
@@ -95,9 +96,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if _build.needs_build():
-        _build.build_library()
-    L = C.CDLL(_build.LIB)
+    path = os.environ.get("WSFLUID_LIBRARY")  # an alternative build of the same ABI (kernel A/B runs)
+    if not path:
+        if _build.needs_build():
+            _build.build_library()
+        path = _build.LIB
+    L = C.CDLL(path)
     vp, u32, fp = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
     L.ws_default_params.argtypes = [C.POINTER(WsParams)]
     L.ws_get_smoothing_kernel.argtypes = [C.POINTER(WsParams), C.POINTER(WsSmoothingKernel)]
@@ -192,7 +196,7 @@ class FluidWorker:
     device buffers, `run()` enqueues one step, `ready()` polls, `read_vec("particles")`
     returns the 80-byte records in original-id order."""
 
-    def __init__(self, positions, params=None, device=0, profile=False, reference_order=False):
+    def __init__(self, positions, params=None, device=0, profile=False, reference_order=False, ieee_division=False):
         self._L = load_library()
         self._h = C.c_void_p()
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -200,7 +204,8 @@ class FluidWorker:
         self.params = params if params is not None else default_params()
         cfg = WsDeviceCfg()
         cfg.device = device
-        cfg.flags = (WS_FLAG_PROFILE if profile else 0) | (WS_FLAG_REFERENCE_ORDER if reference_order else 0)
+        cfg.flags = ((WS_FLAG_PROFILE if profile else 0) | (WS_FLAG_REFERENCE_ORDER if reference_order else 0)
+                     | (WS_FLAG_IEEE_DIVISION if ieee_division else 0))
         st = self._L.ws_create(C.byref(self.params), positions.ctypes.data, self.n, C.byref(cfg), C.byref(self._h))
         if st != 0:
             raise WsError(st, (self._L.ws_last_error(None) or b"").decode())
@@ -299,7 +304,7 @@ class FluidWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        names = ["listed_tiles"]
+        names = ["mask_overflow"]
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def profile(self):
