@@ -611,7 +611,9 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 // Visit order = (dx, dy, z, slot) ascending in every variant: all of them produce the same sums
 // bit for bit.
 // ---------------------------------------------------------------------------------
-#define ND_P 256           // threads per workgroup
+#ifndef ND_P
+#define ND_P 64            // particles per K4 workgroup.  One wave: in the collapsing cloud neighbour counts vary
+#endif                     // 10x between tiles, and a finished wave frees its slot at once (step 60: 0.38 -> 0.29 ms)
 #define ND_K 16            // list fill level that triggers a flush
 #define ND_ROWS (ND_K + 3) // a trip of 4 candidates may start at fill level K-1
 #define ND_MASK_WORDS 64   // 2048 candidates per particle (256 B of mask rows each; only the words in use are touched)
@@ -707,16 +709,20 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     }
 }
 
+#ifndef NF_P
+#define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
+#endif
+
 template <bool IEEE>
-__global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
+__global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                        uint32_t *__restrict__ count, WsMask mask)
 {
     // per-lane run table: candidate numbers [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
-    __shared__ uint32_t t_end[10 * ND_P];  // row 9: a sentinel no candidate number reaches
-    __shared__ uint32_t t_delta[9 * ND_P];
-    const uint32_t i = d.base + blockIdx.x * ND_P + threadIdx.x;
+    __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
+    __shared__ uint32_t t_delta[9 * NF_P];
+    const uint32_t i = d.base + blockIdx.x * NF_P + threadIdx.x;
     const bool valid = i < d.base + d.n;
     const uint32_t iv = valid ? i : d.base + d.n - 1u;
     const float4 o = srt.pred[iv];   // w = own density
@@ -732,11 +738,11 @@ __global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *
         for (int r = 0; r < 9; r++) {
             const int cc = d.guard + c + (r / 3 - 1) * rowy + (r % 3 - 1) * rowz;
             const uint32_t b = valid ? start[cc - 1] : 0u, e = valid ? start[cc + 2] : 0u;
-            t_delta[r * ND_P + threadIdx.x] = b - total;
+            t_delta[r * NF_P + threadIdx.x] = b - total;
             total += e - b;
-            t_end[r * ND_P + threadIdx.x] = total;
+            t_end[r * NF_P + threadIdx.x] = total;
         }
-        t_end[9 * ND_P + threadIdx.x] = 0xFFFFFFFFu;
+        t_end[9 * NF_P + threadIdx.x] = 0xFFFFFFFFu;
     }
     if (!__ballot(total > 32u * ND_MASK_WORDS)) {
         const uint32_t *mrow = mask.words + (iv - d.base);
@@ -758,8 +764,8 @@ __global__ void __launch_bounds__(ND_P) k_force_listed(WsDev d, const uint32_t *
                 word &= word - 1u;
                 while (s >= end_r) {
                     run++;
-                    end_r = t_end[run * ND_P + threadIdx.x];
-                    delta_r = t_delta[min(run, 8u) * ND_P + threadIdx.x];
+                    end_r = t_end[run * NF_P + threadIdx.x];
+                    delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
                 }
                 j = s + delta_r;
                 if (j != i) return true;  // `particle_index == neighbour_index`, simulation.wgsl:232
@@ -816,7 +822,7 @@ static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, c
         hipLaunchKernelGGL((k_force_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
                            cid_srt, srt, out, accel, cid_out, count, mult);
     else
-        hipLaunchKernelGGL((k_force_listed<IEEE>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), 0, s, d, start, cid_srt, srt, out,
+        hipLaunchKernelGGL((k_force_listed<IEEE>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), 0, s, d, start, cid_srt, srt, out,
                            accel, cid_out, count, mask);
 }
 
