@@ -28,7 +28,10 @@ def test_slabs_reproduce_single_gpu_bitwise(ws, world):
     first = np.bincount(ws.slab.assign(params, pos, world), minlength=world)
     assert list(first) != owned, "the test must actually migrate particles"
     for f in want.dtype.names:
-        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+        bad = np.any(got[f].view(np.uint32) != want[f].view(np.uint32), axis=1)
+        assert not bad.any(), "%s: %d particles differ (first ids %s), max |diff| %.3e, x of the first %s" % (
+            f, int(bad.sum()), np.flatnonzero(bad)[:8], float(np.max(np.abs(got[f] - want[f]))),
+            want["position"][np.flatnonzero(bad)[:8], 0])
 
 
 def test_slab_assign_matches_cell_cuts(ws):

@@ -142,9 +142,9 @@ void free_grid(ws_handle *h)
 {
     hipFree(h->count);
     hipFree(h->cursor);
-    hipFree(h->start);
+    hipFree(h->start_alloc);
     hipFree(h->bsum);
-    h->count = h->cursor = h->start = h->bsum = nullptr;
+    h->count = h->cursor = h->start = h->start_alloc = h->bsum = nullptr;
     h->grid_alloc_cells = 0;
 }
 
@@ -158,13 +158,16 @@ ws_status alloc_grid(ws_handle *h)
         h->grid_alloc_cells = d.ncells;
     }
     // start is sized by the guard too, which depends on the dims: always (re)build it
-    hipFree(h->start);
+    hipFree(h->start_alloc);
     hipFree(h->bsum);
-    h->start = h->bsum = nullptr;
+    h->start = h->start_alloc = h->bsum = nullptr;
     const size_t nstart = (size_t)d.ncells + 2 * (size_t)d.guard + 2;
-    HIP_TRY(h, hipMalloc(&h->start, nstart * 4));
-    h->nscan_blocks = wsk_scan_blocks(d.ncells);
-    HIP_TRY(h, hipMalloc(&h->bsum, (size_t)h->nscan_blocks * 4));
+    // the scan writes start's body (from entry `guard`) 16 B at a time: shift the array so that entry is aligned
+    HIP_TRY(h, hipMalloc(&h->start_alloc, (nstart + 4) * 4));
+    h->start = h->start_alloc + (4u - (uint32_t)d.guard % 4u) % 4u;
+    HIP_TRY(h, hipMalloc(&h->bsum, (size_t)wsk_scan_state_words(d.ncells) * 4));
+    HIP_TRY(h, hipMemsetAsync(h->bsum, 0, (size_t)wsk_scan_state_words(d.ncells) * 4, h->stream));  // same stream as its users
+    h->scan_launches = 0;
     // constant parts of cell_start: front guard = 0, [ncells] and the back guard = n
     HIP_TRY(h, hipMemsetAsync(h->start, 0, (size_t)d.guard * 4, h->stream));
     std::vector<uint32_t> tail((size_t)d.guard + 2, d.n);
@@ -275,7 +278,7 @@ void enqueue_step(ws_handle *h)
     hipStream_t s = h->stream;
     {
         Prof p(h, WS_K_SCAN);
-        wsk_scan(s, h->count, h->start + d.guard, h->cursor, h->bsum, d.ncells, h->nscan_blocks, true, 0);
+        wsk_scan(s, h->count, h->start + d.guard, h->cursor, h->bsum, &h->scan_launches, d.ncells, true, 0);
     }
     {
         Prof p(h, WS_K_SCATTER);
@@ -545,7 +548,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->srt.vel, n16));
     CREATE_HIP(hipMalloc(&h->srt.pred, n16));
     CREATE_HIP(hipMalloc(&h->sxyz.x, n16 / 4)); CREATE_HIP(hipMalloc(&h->sxyz.y, n16 / 4)); CREATE_HIP(hipMalloc(&h->sxyz.z, n16 / 4));
-    CREATE_HIP(hipMemset(h->sxyz.x, 0, n16 / 4)); CREATE_HIP(hipMemset(h->sxyz.y, 0, n16 / 4)); CREATE_HIP(hipMemset(h->sxyz.z, 0, n16 / 4));
+    CREATE_HIP(hipMemsetAsync(h->sxyz.x, 0, n16 / 4, h->stream)); CREATE_HIP(hipMemsetAsync(h->sxyz.y, 0, n16 / 4, h->stream)); CREATE_HIP(hipMemsetAsync(h->sxyz.z, 0, n16 / 4, h->stream));
     CREATE_HIP(hipMalloc(&h->cid_cur, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->accel, n16));
@@ -556,7 +559,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
         CREATE_HIP(hipMalloc(&h->mask.words, (size_t)wsk_mask_words() * n * 4));
     }
     CREATE_HIP(hipMalloc(&h->stats, 64));
-    CREATE_HIP(hipMemset(h->stats, 0, 64));
+    CREATE_HIP(hipMemsetAsync(h->stats, 0, 64, h->stream));
     CREATE_TRY(alloc_grid(h));
     CREATE_TRY(upload_mult(h));
     CREATE_TRY(upload_positions(h, pos_xyz));
@@ -785,7 +788,8 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         HIP_TRY(h, hipMalloc(&h->v_cursor, (size_t)n * 4));
         HIP_TRY(h, hipMalloc(&h->v_start, ((size_t)n + 1) * 4));
         HIP_TRY(h, hipMalloc(&h->v_off, (size_t)n * 4));
-        HIP_TRY(h, hipMalloc(&h->v_bsum, (size_t)wsk_scan_blocks(n) * 4));
+        HIP_TRY(h, hipMalloc(&h->v_bsum, (size_t)wsk_scan_state_words(n) * 4));
+        HIP_TRY(h, hipMemsetAsync(h->v_bsum, 0, (size_t)wsk_scan_state_words(n) * 4, h->stream));
         HIP_TRY(h, hipMemcpy(h->v_start + n, &n, 4, hipMemcpyHostToDevice));
     }
     if (h->steps == 0) {
@@ -800,7 +804,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     HIP_TRY(h, hipMemsetAsync(h->v_count, 0, (size_t)n * 4, s));
     // the predicted positions the last step started from live in the sorted copy
     wsk_view_keys(s, h->dev, h->srt.pred, h->srt.pos, h->v_keys, h->v_count);
-    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, n, wsk_scan_blocks(n), false, 0);
+    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, &h->v_scan_launches, n, false, 0);
     wsk_scatter(s, h->v_keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n);
     wsk_view_fix(s, h->v_tmp, h->v_keys, h->v_start, h->v_perm, n);
     wsk_view_offsets(s, h->v_start, h->v_off, n);

@@ -93,8 +93,9 @@ struct ws_handle {
     uint32_t *count = nullptr;    // per-cell particle count (histogram)
     uint32_t *cursor = nullptr;   // per-cell fill cursor
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
-    uint32_t *bsum = nullptr;     // scan block sums
-    uint32_t nscan_blocks = 0;
+    uint32_t *start_alloc = nullptr;  // its allocation (start sits 0..3 words in: see alloc_grid)
+    uint32_t *bsum = nullptr;     // scan state (ticket + tile descriptors), zeroed at allocation
+    uint32_t scan_launches = 0, v_scan_launches = 0;  // scans run on bsum / v_bsum since they were zeroed
     WsMask mask = {nullptr, 0};   // accept masks (listed variant)
     bool ieee = false;            // WS_FLAG_IEEE_DIVISION: correctly rounded sqrt / division in the pair terms
     uint32_t *stats = nullptr;    // device counters: [0] particle-steps with more candidates than the mask holds
@@ -150,9 +151,9 @@ struct WsSlab {
 void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32_t n);
 void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);
 void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count);
-void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *bsum,
-              uint32_t nitems, uint32_t nblocks, bool zero_count, uint32_t base);
-uint32_t wsk_scan_blocks(uint32_t nitems);
+void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t *launches,
+              uint32_t nitems, bool zero_count, uint32_t base);
+uint32_t wsk_scan_state_words(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
                  uint32_t *id_tmp, uint32_t n);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,

@@ -16,10 +16,13 @@
 
 #include "ws_internal.h"
 
+
 #pragma clang fp contract(off)
 
 #define WS_BLOCK 256
-#define WS_SCAN_ITEMS 8
+#ifndef WS_SCAN_ITEMS
+#define WS_SCAN_ITEMS 32  // per thread: the look-back chain is ~1 us per 64 tiles, so few large tiles (C3: 8/16/32 -> 54/39/32 us)
+#endif
 #define WS_SCAN_TILE (WS_BLOCK * WS_SCAN_ITEMS)
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -176,87 +179,126 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total)
     return base + incl - v;
 }
 
-__device__ __forceinline__ void load_tile(const uint32_t *__restrict__ src, uint32_t nitems, uint32_t v[WS_SCAN_ITEMS])
-{
-    const uint32_t base = blockIdx.x * WS_SCAN_TILE + threadIdx.x * WS_SCAN_ITEMS;
-    if (base + WS_SCAN_ITEMS <= nitems) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(src + base);
-        const uint4 b = *reinterpret_cast<const uint4 *>(src + base + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < WS_SCAN_ITEMS; k++) v[k] = (base + k < nitems) ? src[base + k] : 0u;
-    }
-}
-
-__global__ void __launch_bounds__(WS_BLOCK) k_scan_reduce(const uint32_t *__restrict__ count, uint32_t nitems,
-                                                          uint32_t *__restrict__ bsum)
-{
-    uint32_t v[WS_SCAN_ITEMS];
-    load_tile(count, nitems, v);
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < WS_SCAN_ITEMS; k++) s += v[k];
-    uint32_t total;
-    block_excl_scan(s, &total);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
-}
-
-// single block: in-place exclusive scan of the block sums
-__global__ void __launch_bounds__(WS_BLOCK) k_scan_top(uint32_t *__restrict__ bsum, uint32_t nblocks)
-{
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += WS_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < nblocks) ? bsum[i] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, &total);
-        if (i < nblocks) bsum[i] = carry + ex;
-        carry += total;
-    }
-}
-
+// One-pass exclusive scan (decoupled look-back): tile t publishes its aggregate, then walks back over its
+// predecessors' descriptors until it meets an inclusive prefix, and publishes its own.  Tiles take their
+// index from a ticket counter, so every predecessor of a running tile is itself running or done: the
+// wait cannot deadlock.  state[0] = ticket counter, never reset: launch number `epoch` (counted per buffer
+// by the owner, from 1) hands out tickets epoch * ntiles ... in modular arithmetic.  64-bit descriptors from
+// state[2]: hi = epoch << 2 | status (1 = aggregate, 2 = inclusive prefix), lo = value.  A descriptor of
+// another epoch reads as "not yet written", so nothing is cleared between launches.  A descriptor carries its
+// whole message in one 64-bit word, so relaxed device-scope atomics suffice (acquire / release at agent scope
+// would write back and invalidate the XCD's L2 around every access: measured 8x slower).
 template <bool ZERO>
-__global__ void __launch_bounds__(WS_BLOCK) k_scan_apply(uint32_t *__restrict__ count, uint32_t nitems,
-                                                         const uint32_t *__restrict__ bsum,
-                                                         uint32_t *__restrict__ start, uint32_t *__restrict__ cursor,
-                                                         uint32_t start_offset)
+__global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count, uint32_t nitems,
+                                                   uint32_t *__restrict__ state, uint32_t *__restrict__ start,
+                                                   uint32_t *__restrict__ cursor, uint32_t start_offset, uint32_t epoch,
+                                                   uint32_t ntiles)
 {
-    uint32_t v[WS_SCAN_ITEMS];
-    load_tile(count, nitems, v);
-    uint32_t s = 0;
+    __shared__ uint32_t s_tile, s_prefix;
+    if (threadIdx.x == 0) {
+        s_tile = atomicAdd(&state[0], 1u) - (epoch - 1u) * ntiles;
+    }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    // A tile is WS_SCAN_ITEMS / 4 chunks of WS_BLOCK uint4: thread t owns uint4 number t of every chunk, so
+    // every load and store of the tile is a coalesced 16 B per lane.
+    constexpr int Q = WS_SCAN_ITEMS / 4;
+    const uint32_t tbase = tile * WS_SCAN_TILE;
+    uint4 v[Q];
+    uint32_t excl[Q], total = 0;
 #pragma unroll
-    for (int k = 0; k < WS_SCAN_ITEMS; k++) s += v[k];
-    uint32_t total;
-    uint32_t run = block_excl_scan(s, &total) + bsum[blockIdx.x] + start_offset;
-    const uint32_t base = blockIdx.x * WS_SCAN_TILE + threadIdx.x * WS_SCAN_ITEMS;
-#pragma unroll
-    for (int k = 0; k < WS_SCAN_ITEMS; k++) {
-        if (base + k < nitems) {
-            start[base + k] = run;
-            cursor[base + k] = run;
-            if (ZERO) count[base + k] = 0u;
+    for (int q = 0; q < Q; q++) {
+        const uint32_t at = tbase + (q * WS_BLOCK + threadIdx.x) * 4u;
+        if (at + 4u <= nitems) {
+            v[q] = *reinterpret_cast<const uint4 *>(count + at);
+        } else {
+            v[q].x = at < nitems ? count[at] : 0u;
+            v[q].y = at + 1u < nitems ? count[at + 1u] : 0u;
+            v[q].z = at + 2u < nitems ? count[at + 2u] : 0u;
+            v[q].w = 0u;
         }
-        run += v[k];
+        uint32_t chunk_total;
+        excl[q] = total + block_excl_scan(v[q].x + v[q].y + v[q].z + v[q].w, &chunk_total);
+        total += chunk_total;
+    }
+    if (threadIdx.x < 64) {
+        // wave 0 looks back 64 predecessors at a time (one memory round trip per window)
+        unsigned long long *desc = reinterpret_cast<unsigned long long *>(state + 2);
+        const uint32_t e30 = epoch & 0x3FFFFFFFu;
+        const unsigned long long tag = (unsigned long long)(e30 << 2) << 32;
+        const int lane = (int)threadIdx.x;
+        uint32_t prefix = 0;
+        if (tile != 0u) {
+            if (lane == 0)
+                __hip_atomic_store(&desc[tile], tag | (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int32_t newest = (int32_t)tile - 1;;) {
+                const int32_t p = newest - lane;  // lane 0 = the nearest predecessor of this window
+                // tiles "before the first" count as an inclusive prefix of 0, which ends every walk
+                const unsigned long long dsc =
+                    p >= 0 ? __hip_atomic_load(&desc[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | (2ull << 32));
+                const uint32_t hi = (uint32_t)(dsc >> 32);
+                const bool ready = (hi >> 2) == e30 && (hi & 3u) != 0u;
+                const unsigned long long inclusive = __ballot(ready && (hi & 3u) == 2u);
+                const int stop = inclusive ? __ffsll((long long)inclusive) - 1 : 63;  // last lane whose value counts
+                const unsigned long long needed = stop == 63 ? ~0ull : (2ull << stop) - 1ull;
+                if (__ballot(!ready) & needed) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;  // somebody this walk depends on has not published yet: same window again
+                }
+                uint32_t v = lane <= stop ? (uint32_t)dsc : 0u;
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
+                prefix += v;
+                if (inclusive) break;
+                newest -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&desc[tile], tag | (2ull << 32) | (prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
+    }
+    __syncthreads();
+    const uint32_t carry = s_prefix + start_offset;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const uint32_t at = tbase + (q * WS_BLOCK + threadIdx.x) * 4u;
+        uint4 r;
+        r.x = carry + excl[q];
+        r.y = r.x + v[q].x;
+        r.z = r.y + v[q].y;
+        r.w = r.z + v[q].z;
+        if (at + 4u <= nitems) {
+            *reinterpret_cast<uint4 *>(start + at) = r;
+            *reinterpret_cast<uint4 *>(cursor + at) = r;
+            if (ZERO) *reinterpret_cast<uint4 *>(count + at) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            const uint32_t rr[3] = {r.x, r.y, r.z};
+            for (uint32_t k = 0; k < 3u && at + k < nitems; k++) {
+                start[at + k] = rr[k];
+                cursor[at + k] = rr[k];
+                if (ZERO) count[at + k] = 0u;
+            }
+        }
     }
 }
 
-uint32_t wsk_scan_blocks(uint32_t nitems) { return cdiv(nitems, WS_SCAN_TILE); }
+// words of scan state for `nitems` items (zero-initialised once by the owner)
+uint32_t wsk_scan_state_words(uint32_t nitems) { return 2u + 2u * cdiv(nitems, WS_SCAN_TILE); }
 
 // start_body points at the first real entry (after the guard); entry [nitems] and the
 // guards are constant and written once by the host.
-void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *bsum,
-              uint32_t nitems, uint32_t nblocks, bool zero_count, uint32_t base)
+void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state,
+              uint32_t *launches, uint32_t nitems, bool zero_count, uint32_t base)
 {
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblocks), dim3(WS_BLOCK), 0, s, count, nitems, bsum);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(WS_BLOCK), 0, s, bsum, nblocks);
+    const uint32_t epoch = ++*launches;  // per state buffer, from 1
+    const uint32_t ntiles = cdiv(nitems, WS_SCAN_TILE);
     if (zero_count)
-        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nblocks), dim3(WS_BLOCK), 0, s, count, nitems, bsum, start_body,
-                           cursor, base);
+        hipLaunchKernelGGL(k_scan<true>, dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor,
+                           base, epoch, ntiles);
     else
-        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nblocks), dim3(WS_BLOCK), 0, s, count, nitems, bsum, start_body,
-                           cursor, base);
+        hipLaunchKernelGGL(k_scan<false>, dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor,
+                           base, epoch, ntiles);
 }
 
 // ---------------------------------------------------------------------------------
