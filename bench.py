@@ -69,14 +69,20 @@ def cpu_baseline(pos, params, steps):
     }
 
 
-def load_traffic(config, dist):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
+KERNEL_LABEL = {
+    "density": "density (K4 update_density: radius sweep + accept masks)",
+    "force_integrate_bin": "force_integrate_bin (K5 update_pressure_force + K6 integrate + next K1 binning)",
+}
+
+
+def load_traffic(config, dist, kernel):
+    """HBM bytes per launch of `kernel` from committed rocprofv3 --pmc passes
     (profiles/traffic.json), or None if no measurement for this workload is committed."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return t.get("%s-%s" % (config, dist), {}).get("force_integrate_bin_bytes_per_launch")
+        return t.get("%s-%s" % (config, dist), {}).get("bytes_per_launch", {}).get(kernel)
     except (OSError, ValueError):
         return None
 
@@ -109,6 +115,8 @@ def main():
         # group for the few control words per step (DESIGN.md "Multi-GPU").
         import torch.distributed as dist
 
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
+            os.environ.setdefault(k, v)  # the one-rank rehearsal (WS_BENCH_FORCE_SLAB=1) without a launcher
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         ctrl = dist.new_group(backend="gloo")
         # the library enqueues on the stream RCCL's point-to-point calls are ordered on: an explicit,
@@ -124,9 +132,10 @@ def main():
         pos, params = ws.workloads.make_workload(args.config, args.dist)
         n_global = n_rank = pos.shape[0]
         worker = ws.FluidWorker(pos, params, device=local_rank, profile=True)
-        # HIP events bracket ONLY the dominant kernel inside the timed region (2 records per step, on the
-        # library's own stream): bracketing all seven launches costs ~7 % of a 1.4 ms step
-        worker.profile_select(1 << ws.fluid.KERNEL_IDS["force_integrate_bin"])
+        # HIP events bracket only the two neighbour kernels inside the timed region (4 records per step, on the
+        # library's own stream): one of them is the dominant kernel, and bracketing all five launches costs
+        # several per cent of a sub-millisecond step
+        worker.profile_select((1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"]))
 
     def barrier():
         worker.sync()
@@ -146,7 +155,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = worker.profile()
-    force_ms, force_cnt = prof["force_integrate_bin"]
+    dominant = max(("density", "force_integrate_bin"), key=lambda k: prof[k][0])
+    force_ms, force_cnt = prof[dominant]
     breakdown = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]}
     owned = worker.num_owned() if distributed else n_rank
     if args.breakdown and not distributed and rank == 0:
@@ -164,7 +174,7 @@ def main():
         # world x global steps/s.  At world = 1 this is plain simulation steps/s.
         value = world * global_steps_per_s
         force_avg_s = force_ms / max(force_cnt, 1) * 1e-3
-        alg_bytes = KERNEL_ALG_BYTES["force_integrate_bin"] * owned
+        alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
         achieved = alg_bytes / force_avg_s / 1e9
         dist_name = ("uniform cloud seed 0x%X" % ws.workloads.cloud_seed(args.config)) if args.dist == "cloud" \
             else "cube_fluid lattice"
@@ -196,13 +206,13 @@ def main():
             "particle_steps_per_s": global_steps_per_s * n_global,
             "algorithmic_GBps_step": B_ALG_STEP * n_global * global_steps_per_s / 1e9,
             "roofline": {
-                "kernel": "force_integrate_bin (K5 update_pressure_force + K6 integrate + next K1 binning)",
+                "kernel": KERNEL_LABEL[dominant],
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(args.config, args.dist) if not distributed else None,
+                "traffic": load_traffic(args.config, args.dist, dominant) if not distributed else None,
                 "alg_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": force_avg_s * 1e3,
                 "launches_timed": force_cnt,

@@ -12,7 +12,10 @@ rm -rf $GRAFT_REPO_ROOT/$out/rocprof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rocprof_bench -- python3 bench.py --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof_bench.err
 tools/traffic.sh c3 cloud 10 100
 : > $out/variants.log
-for v in simple listed; do for w in 10 200; do
-  WS_VARIANT=$v python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' | sed "s/\"variant\": \"[a-z]*\"/\"variant\": \"$v\"/" >> $out/variants.log
-done; done
+for w in 10 60 200; do
+  WS_VARIANT=simple python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
+  WS_VARIANT=simple WS_IEEE=1 python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
+  python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
+  WS_IEEE=1 python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
+done
 echo done

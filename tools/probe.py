@@ -13,7 +13,8 @@ dist = sys.argv[2] if len(sys.argv) > 2 else "cloud"
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 pos, params = ws.workloads.make_workload(cfg, dist)
-w = ws.FluidWorker(pos, params, profile=True)
+ieee = os.environ.get("WS_IEEE", "0") == "1"  # WS_FLAG_IEEE_DIVISION
+w = ws.FluidWorker(pos, params, profile=True, ieee_division=ieee)
 w.profile_select(0)
 w.run(warm)
 w.sync()
@@ -22,6 +23,6 @@ w.profile_reset()
 w.run(steps)
 w.sync()
 prof = {k: round(v[0] / max(v[1], 1), 4) for k, v in w.profile().items() if v[1]}
-print(json.dumps({"variant": os.environ.get("WS_VARIANT", "listed"), "config": cfg, "dist": dist, "warmup": warm,
+print(json.dumps({"variant": os.environ.get("WS_VARIANT", "listed") + ("+ieee" if ieee else ""), "config": cfg, "dist": dist, "warmup": warm,
                   "steps": steps, "ms": prof, "total_ms": round(sum(prof.values()), 4), "stats": w.stats()}))
 w.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer probe: wall-clock ms/step without any profiling events (so the hipGraph path is taken).
-usage: wall.py [config] [dist] [warmup] [steps]   (WS_GRAPH=0 disables graph replay)"""
+"""Developer probe: wall-clock ms/step without any profiling events.
+usage: wall.py [config] [dist] [warmup] [steps]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import water_sandbox_amd as ws
@@ -12,6 +12,6 @@ pos, params = ws.workloads.make_workload(cfg, dist)
 w = ws.FluidWorker(pos, params)
 w.run(warm); w.sync()
 t0 = time.perf_counter(); w.run(steps); w.sync(); dt = time.perf_counter() - t0
-print(json.dumps({"graph": os.environ.get("WS_GRAPH", "1"), "config": cfg, "dist": dist, "warmup": warm, "steps": steps,
+print(json.dumps({"config": cfg, "dist": dist, "warmup": warm, "steps": steps,
                   "ms_per_step": round(dt / steps * 1e3, 4)}))
 w.close()
