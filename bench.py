@@ -132,10 +132,10 @@ def main():
         pos, params = ws.workloads.make_workload(args.config, args.dist)
         n_global = n_rank = pos.shape[0]
         worker = ws.FluidWorker(pos, params, device=local_rank, profile=True)
-        # HIP events bracket only the two neighbour kernels inside the timed region (4 records per step, on the
-        # library's own stream): one of them is the dominant kernel, and bracketing all five launches costs
-        # several per cent of a sub-millisecond step
-        worker.profile_select((1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"]))
+    # HIP events bracket only the two neighbour kernels inside the timed region (4 records per step, on the
+    # library's stream): one of them is the dominant kernel, and bracketing all five launches costs several
+    # per cent of a sub-millisecond step
+    worker.profile_select((1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"]))
 
     def barrier():
         worker.sync()

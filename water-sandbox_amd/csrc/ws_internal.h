@@ -141,7 +141,9 @@ struct WsSlab {
     bool binned = false;              // cid_cur / count describe the current owned set
     float4 *mig_send = nullptr, *mig_all = nullptr;
     uint32_t *tmpL = nullptr, *tmpR = nullptr;
-    uint32_t *host_pin = nullptr;     // pinned scratch for small device->host reads
+    uint32_t *host_pin = nullptr;     // pinned: migration matrix [W*W], then the boundary table [4W]
+    hipEvent_t ev_mark = nullptr, ev_bnd = nullptr;  // their copies have landed
+    bool mark_pending = false;        // slab_mark already enqueued for the next step
     uint32_t gL = 0, gR = 0;          // ghosts currently staged in front of / behind the owned range
     // cumulative statistics
     uint64_t migrated_out = 0, ghosts_in = 0;

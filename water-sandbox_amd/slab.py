@@ -297,6 +297,9 @@ class SlabWorker:
     def profile_reset(self):
         self._check(self._L.ws_profile_reset(self._h))
 
+    def profile_select(self, mask):
+        self._check(self._L.ws_profile_select(self._h, mask & 0xFFFFFFFF))
+
     def close(self):
         if self._h:
             self._L.ws_destroy(self._h)
