@@ -195,11 +195,12 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  * the scale-out row of SURVEY.md 8(e). */
 typedef struct ws_transport {
     void *ctx;
-    /* Stream-ordered exchange with the x-neighbours d = 0 (rank - 1) and d = 1 (rank + 1): send
-     * send_bytes[d] bytes from DEVICE pointer send_ptr[d], receive recv_bytes[d] bytes into DEVICE
-     * pointer recv_ptr[d].  Zero bytes = no transfer in that direction.  Returns 0 on success. */
-    int (*sendrecv)(void *ctx, void *const send_ptr[2], const uint64_t send_bytes[2], void *const recv_ptr[2],
-                    const uint64_t recv_bytes[2], void *stream);
+    /* Stream-ordered exchange of nseg buffers with each x-neighbour, d = 0 (rank - 1) and d = 1 (rank + 1), as
+     * ONE group of point-to-point transfers: for segment k send send_bytes[2k + d] bytes from DEVICE pointer
+     * send_ptr[2k + d] and receive recv_bytes[2k + d] bytes into DEVICE pointer recv_ptr[2k + d].  Zero bytes =
+     * no transfer.  Both sides list their segments in the same order.  Returns 0 on success. */
+    int (*sendrecv)(void *ctx, uint32_t nseg, void *const send_ptr[], const uint64_t send_bytes[],
+                    void *const recv_ptr[], const uint64_t recv_bytes[], void *stream);
     /* Stream-ordered all-gather of bytes_each DEVICE bytes per rank into recv_ptr[world_size * bytes_each]. */
     int (*allgather_dev)(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream);
 } ws_transport;

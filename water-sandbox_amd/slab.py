@@ -19,8 +19,8 @@ import numpy as np
 
 from . import fluid
 
-SENDRECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
-                         C.POINTER(C.c_uint64), C.c_void_p)
+SENDRECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p)
 ALLGATHER_U32_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32))
 ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
@@ -57,8 +57,10 @@ class _TransportBase:
             self.error = e
             return 1
 
-    def _c_sendrecv(self, ctx, sp, sb, rp, rb, stream):
-        return self._guard(self.sendrecv, [sp[0], sp[1]], [sb[0], sb[1]], [rp[0], rp[1]], [rb[0], rb[1]], stream)
+    def _c_sendrecv(self, ctx, nseg, sp, sb, rp, rb, stream):
+        m = 2 * nseg  # entry 2k + d: segment k, direction d (0 = left neighbour, 1 = right neighbour)
+        return self._guard(self.sendrecv, [sp[i] for i in range(m)], [sb[i] for i in range(m)],
+                           [rp[i] for i in range(m)], [rb[i] for i in range(m)], stream)
 
     def _c_allgather_u32(self, ctx, inp, count, out):
         def run():
@@ -106,12 +108,13 @@ class TorchDistTransport(_TransportBase):
     def sendrecv(self, sp, sb, rp, rb, stream):
         dist = self.dist
         ops, keep = [], []
-        for d, peer in ((0, self.rank - 1), (1, self.rank + 1)):
-            if sb[d]:
-                t = self._tensor(sp[d], sb[d]); keep.append(t)
+        for i in range(len(sb)):  # segments in order; every pair of neighbours lists them identically
+            peer = self.rank - 1 if i % 2 == 0 else self.rank + 1
+            if sb[i]:
+                t = self._tensor(sp[i], sb[i]); keep.append(t)
                 ops.append(dist.P2POp(dist.isend, t, peer, group=self.data_group))
-            if rb[d]:
-                t = self._tensor(rp[d], rb[d]); keep.append(t)
+            if rb[i]:
+                t = self._tensor(rp[i], rb[i]); keep.append(t)
                 ops.append(dist.P2POp(dist.irecv, t, peer, group=self.data_group))
         if ops:
             self._fence()
@@ -205,14 +208,14 @@ class _LoopbackTransport(_TransportBase):
         hub.hip.hipStreamSynchronize(stream)  # my boundary data is final before anybody reads it
         hub.slots[self.rank] = (sp, sb)
         hub.barrier.wait()
-        if rb[0]:
-            psp, psb = hub.slots[self.rank - 1]
-            assert psb[1] == rb[0], "left neighbour sends %d bytes, I expect %d" % (psb[1], rb[0])
-            hub.copy(rp[0], psp[1], rb[0])
-        if rb[1]:
-            psp, psb = hub.slots[self.rank + 1]
-            assert psb[0] == rb[1], "right neighbour sends %d bytes, I expect %d" % (psb[0], rb[1])
-            hub.copy(rp[1], psp[0], rb[1])
+        for i in range(len(rb)):
+            if not rb[i]:
+                continue
+            d = i % 2  # my left neighbour's right-going segment is entry i + 1 of its lists, and vice versa
+            psp, psb = hub.slots[self.rank - 1 if d == 0 else self.rank + 1]
+            j = i + 1 if d == 0 else i - 1
+            assert psb[j] == rb[i], "neighbour sends %d bytes, I expect %d" % (psb[j], rb[i])
+            hub.copy(rp[i], psp[j], rb[i])
         hub.barrier.wait()  # nobody reuses a send range before every reader is done
 
     def allgather_u32(self, values):
