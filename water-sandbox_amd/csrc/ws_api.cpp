@@ -357,7 +357,7 @@ void free_all(ws_handle *h)
     for (auto e : h->pool) hipEventDestroy(e);
     free_grid(h);
     hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
-    hipFree(h->srt.pos); hipFree(h->srt.vel); hipFree(h->srt.pred);
+    hipFree(h->srt.pos); hipFree(h->srt.pv);
     hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
     hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->mask.words); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
@@ -545,8 +545,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->cur.vel, n16));
     CREATE_HIP(hipMalloc(&h->cur.pred, n16));
     CREATE_HIP(hipMalloc(&h->srt.pos, n16));
-    CREATE_HIP(hipMalloc(&h->srt.vel, n16));
-    CREATE_HIP(hipMalloc(&h->srt.pred, n16));
+    CREATE_HIP(hipMalloc(&h->srt.pv, 2 * n16));
     CREATE_HIP(hipMalloc(&h->sxyz.x, n16 / 4)); CREATE_HIP(hipMalloc(&h->sxyz.y, n16 / 4)); CREATE_HIP(hipMalloc(&h->sxyz.z, n16 / 4));
     CREATE_HIP(hipMemsetAsync(h->sxyz.x, 0, n16 / 4, h->stream)); CREATE_HIP(hipMemsetAsync(h->sxyz.y, 0, n16 / 4, h->stream)); CREATE_HIP(hipMemsetAsync(h->sxyz.z, 0, n16 / 4, h->stream));
     CREATE_HIP(hipMalloc(&h->cid_cur, (size_t)n * 4));
@@ -803,7 +802,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     }
     HIP_TRY(h, hipMemsetAsync(h->v_count, 0, (size_t)n * 4, s));
     // the predicted positions the last step started from live in the sorted copy
-    wsk_view_keys(s, h->dev, h->srt.pred, h->srt.pos, h->v_keys, h->v_count);
+    wsk_view_keys(s, h->dev, h->srt, h->v_keys, h->v_count);
     wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, &h->v_scan_launches, n, false, 0);
     wsk_scatter(s, h->v_keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n);
     wsk_view_fix(s, h->v_tmp, h->v_keys, h->v_start, h->v_perm, n);

@@ -59,6 +59,17 @@ struct WsRef {
 };
 
 // planar copy of the sorted predicted positions (K4's radius tests)
+// The cell-sorted copy.  Predicted position and velocity are interleaved: a neighbour's {pred.xyz, density}
+// and {vel.xyz, near density} are the two halves of ONE 32-byte record, so the force kernel's two 16-B gathers per
+// neighbour hit the same cache line (C3 dense state: -17 % kernel time against two separate arrays), and a halo
+// message is one range.
+struct WsSorted {
+    float4 *pos;  // xyz = position, w = particle id (bits); only the integrator reads it
+    float4 *pv;   // [2j] = {pred.xyz, density after K4}, [2j + 1] = {vel.xyz, near density after K4}
+    __host__ __device__ float4 &pred(uint32_t j) const { return pv[2 * (size_t)j]; }
+    __host__ __device__ float4 &vel(uint32_t j) const { return pv[2 * (size_t)j + 1]; }
+};
+
 struct WsXYZ {
     float *x = nullptr, *y = nullptr, *z = nullptr;
 };
@@ -82,11 +93,11 @@ struct ws_handle {
     bool done_recorded = false;
 
     WsSoA cur{};   // state in the order of the last step (written by the force kernel)
-    WsSoA srt{};   // cell-sorted copy the density/force kernels read
+    WsSorted srt{};  // cell-sorted copy the density/force kernels read
     WsXYZ sxyz;                   // planar predicted positions in `srt` order
     uint32_t *cid_cur = nullptr;  // cell id per particle of `cur`
     uint32_t *cid_srt = nullptr;  // cell id per particle of `srt`
-    int variant = WS_VARIANT_LISTED;  // density / near density ride in srt.pred[i].w / srt.vel[i].w
+    int variant = WS_VARIANT_LISTED;  // density / near density ride in srt.pred(i).w / srt.vel(i).w
     float4 *accel = nullptr;      // acceleration in `srt` order
     uint32_t *slot_tmp = nullptr; // particle index per tentative slot
     uint32_t *id_tmp = nullptr;   // particle id per tentative slot (canonical in-cell order)
@@ -159,20 +170,19 @@ uint32_t wsk_scan_state_words(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
                  uint32_t *id_tmp, uint32_t n);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt, WsXYZ sxyz);
-void wsk_unpack_xyz(hipStream_t s, const float4 *pred, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1);
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz);
+void wsk_unpack_xyz(hipStream_t s, WsSorted srt, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1);
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz);
 uint32_t wsk_mask_words(void);
-void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
+void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
                WsMask mask);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
-void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                           ws_particle80 *out, uint32_t n);
 // reference-layout view
-void wsk_view_keys(hipStream_t s, const WsDev &d, const float4 *pred, const float4 *pos_with_id,
-                   uint32_t *keys_by_id, uint32_t *count);
+void wsk_view_keys(hipStream_t s, const WsDev &d, WsSorted srt, uint32_t *keys_by_id, uint32_t *count);
 void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, const uint32_t *start,
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
@@ -192,6 +202,6 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t n_old, uint32_t n_
                       const uint32_t *leave_matrix, uint32_t me, uint32_t *tgt, uint32_t *src, uint32_t *cnt, WsSoA cur,
                       uint32_t *cid_cur, uint32_t *count);
 void wsk_pick4(hipStream_t s, const uint32_t *start, const uint32_t idx[4], uint32_t *out);
-void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids);
 void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);

@@ -334,7 +334,7 @@ void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id,
 __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *__restrict__ slot_tmp,
                                                       const uint32_t *__restrict__ id_tmp,
                                                       const uint32_t *__restrict__ cid_cur,
-                                                      const uint32_t *__restrict__ start, WsSoA cur, WsSoA srt,
+                                                      const uint32_t *__restrict__ start, WsSoA cur, WsSorted srt,
                                                       uint32_t *__restrict__ cid_srt, WsXYZ sxyz)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
@@ -349,8 +349,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     const uint32_t dst = b + rank;
     const float4 q = cur.pred[i];
     srt.pos[dst] = cur.pos[i];
-    srt.vel[dst] = cur.vel[i];
-    srt.pred[dst] = q;
+    srt.vel(dst) = cur.vel[i];
+    srt.pred(dst) = q;
     // K4's radius tests read the predicted positions as three planar arrays: one 16-B load there
     // fetches x (or y, z) of FOUR consecutive candidates
     sxyz.x[dst] = q.x;
@@ -360,29 +360,29 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
 }
 
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSoA srt, uint32_t *cid_srt, WsXYZ sxyz)
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz)
 {
     hipLaunchKernelGGL(k_reorder, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur, start,
                        cur, srt, cid_srt, sxyz);
 }
 
 // slabs: planar copy of the ghost layers' predicted positions after halo A ([lo0, hi0) and [lo1, hi1))
-__global__ void __launch_bounds__(WS_BLOCK) k_unpack_xyz(const float4 *__restrict__ pred, WsXYZ sxyz, uint32_t lo0,
+__global__ void __launch_bounds__(WS_BLOCK) k_unpack_xyz(WsSorted srt, WsXYZ sxyz, uint32_t lo0,
                                                          uint32_t n0, uint32_t lo1, uint32_t n1)
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (t >= n0 + n1) return;
     const uint32_t i = t < n0 ? lo0 + t : lo1 + (t - n0);
-    const float4 q = pred[i];
+    const float4 q = srt.pred(i);
     sxyz.x[i] = q.x;
     sxyz.y[i] = q.y;
     sxyz.z[i] = q.z;
 }
 
-void wsk_unpack_xyz(hipStream_t s, const float4 *pred, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1)
+void wsk_unpack_xyz(hipStream_t s, WsSorted srt, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1)
 {
     if (n0 + n1 == 0) return;
-    hipLaunchKernelGGL(k_unpack_xyz, dim3(cdiv(n0 + n1, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pred, sxyz, lo0, n0, lo1, n1);
+    hipLaunchKernelGGL(k_unpack_xyz, dim3(cdiv(n0 + n1, WS_BLOCK)), dim3(WS_BLOCK), 0, s, srt, sxyz, lo0, n0, lo1, n1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -504,12 +504,12 @@ __device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, f
 // particle's sorted predicted position and velocity, so K5 gets {pred.xyz, density} and
 // {vel.xyz, near density} of a neighbour in two 16-B loads.  Other workgroups are still
 // reading pred.xyz while this w is written: different floats, never the same memory location.
-__device__ __forceinline__ void density_store(float density, float near_density, uint32_t i, WsSoA srt)
+__device__ __forceinline__ void density_store(float density, float near_density, uint32_t i, WsSorted srt)
 {
     density = density + 0.00001f;  // DENSITY_PADDING, simulation.wgsl:4,187-188
     near_density = near_density + 0.00001f;
-    reinterpret_cast<float *>(srt.pred + i)[3] = density;
-    reinterpret_cast<float *>(srt.vel + i)[3] = near_density;
+    srt.pred(i).w = density;
+    srt.vel(i).w = near_density;
 }
 
 // K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
@@ -553,7 +553,7 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
 // and the fallback of the listed K5 for particles whose neighbour list overflowed.
 // ---------------------------------------------------------------------------------
 template <bool ALIAS, bool IEEE>
-__device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSoA srt,
+__device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSorted srt,
                                                      const uint8_t *__restrict__ mult, float4 o, int c, float &density,
                                                      float &near_density)
 {
@@ -563,7 +563,7 @@ __device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint3
             const int cc = d.guard + c + dx * rowy + dy * rowz;
             const uint32_t b = start[cc - 1], e = start[cc + 2];
             for (uint32_t j = b; j < e; j++) {
-                const float4 q = srt.pred[j];
+                const float4 q = srt.pred(j);
                 const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
                 const float d2 = ex * ex + ey * ey + ez * ez;
                 if (d2 > d.d2_accept) continue;
@@ -574,7 +574,7 @@ __device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint3
 }
 
 template <bool ALIAS, bool IEEE>
-__device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSoA srt,
+__device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSorted srt,
                                                    const uint8_t *__restrict__ mult, uint32_t i, float4 o, float4 vel, int c,
                                                    float pressure, float near_pressure, ForceAcc &acc)
 {
@@ -585,11 +585,11 @@ __device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_
             const uint32_t b = start[cc - 1], e = start[cc + 2];
             for (uint32_t j = b; j < e; j++) {
                 if (j == i) continue;  // `particle_index == neighbour_index`, simulation.wgsl:232
-                const float4 q = srt.pred[j];
+                const float4 q = srt.pred(j);
                 const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
                 const float d2 = ex * ex + ey * ey + ez * ez;
                 if (d2 > d.d2_accept) continue;
-                const float4 nvel = srt.vel[j];
+                const float4 nvel = srt.vel(j);
                 force_pair<IEEE>(d, ex, ey, ez, d2, q.w, nvel.w, nvel, vel, pressure, near_pressure, acc,
                                  ALIAS ? alias_mult(d, mult, o, q) : 1u);
             }
@@ -599,26 +599,26 @@ __device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_
 
 template <bool ALIAS, bool IEEE>
 __global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint32_t *__restrict__ start,
-                                                             const uint32_t *__restrict__ cid_srt, WsSoA srt,
+                                                             const uint32_t *__restrict__ cid_srt, WsSorted srt,
                                                              const uint8_t *__restrict__ mult)
 {
     const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= d.base + d.n) return;
     float density = 0.f, near_density = 0.f;
-    density_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, srt.pred[i], (int)cid_srt[i], density, near_density);
+    density_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, srt.pred(i), (int)cid_srt[i], density, near_density);
     density_store(density, near_density, i, srt);
 }
 
 template <bool ALIAS, bool IEEE>
 __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32_t *__restrict__ start,
-                                                           const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
+                                                           const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                            float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                            uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
 {
     const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= d.base + d.n) return;
-    const float4 o = srt.pred[i];    // w = own density
-    const float4 vel = srt.vel[i];   // w = own near density
+    const float4 o = srt.pred(i);    // w = own density
+    const float4 vel = srt.vel(i);   // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
     const float near_pressure = d.near_pressure_scalar * vel.w;
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -698,14 +698,14 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
 
 template <bool IEEE>
 __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ start,
-                                                         const uint32_t *__restrict__ cid_srt, WsSoA srt, WsXYZ sxyz,
+                                                         const uint32_t *__restrict__ cid_srt, WsSorted srt, WsXYZ sxyz,
                                                          WsMask mask, uint32_t *__restrict__ stats)
 {
     __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
     const uint32_t i = d.base + blockIdx.x * ND_P + threadIdx.x;
     const bool valid = i < d.base + d.n;
     const uint32_t iv = valid ? i : d.base + d.n - 1u;
-    const float4 o = srt.pred[iv];
+    const float4 o = make_float4(sxyz.x[iv], sxyz.y[iv], sxyz.z[iv], 0.f);  // the planar copy: coalesced, same bits
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
     float density = 0.f, near_density = 0.f;
@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 
 template <bool IEEE>
 __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
-                                                       const uint32_t *__restrict__ cid_srt, WsSoA srt, WsSoA out,
+                                                       const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                        uint32_t *__restrict__ count, WsMask mask)
 {
@@ -767,8 +767,8 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     const uint32_t i = d.base + blockIdx.x * NF_P + threadIdx.x;
     const bool valid = i < d.base + d.n;
     const uint32_t iv = valid ? i : d.base + d.n - 1u;
-    const float4 o = srt.pred[iv];   // w = own density
-    const float4 vel = srt.vel[iv];  // w = own near density
+    const float4 o = srt.pred(iv);   // w = own density
+    const float4 vel = srt.vel(iv);  // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
     const float near_pressure = d.near_pressure_scalar * vel.w;
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -817,12 +817,12 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         // iterator has already produced k+2.  Exhausted lanes load their own record (always a valid address).
         uint32_t j1 = iv, j2 = iv;
         bool have0 = next(j1);
-        float4 q_next = srt.pred[have0 ? j1 : iv], nvel_next = srt.vel[have0 ? j1 : iv];
+        float4 q_next = srt.pred(have0 ? j1 : iv), nvel_next = srt.vel(have0 ? j1 : iv);
         bool have1 = have0 && next(j2);
         while (have0) {
             const float4 q = q_next, nvel = nvel_next;
-            q_next = srt.pred[have1 ? j2 : iv];
-            nvel_next = srt.vel[have1 ? j2 : iv];
+            q_next = srt.pred(have1 ? j2 : iv);
+            nvel_next = srt.vel(have1 ? j2 : iv);
             have0 = have1;
             have1 = have1 && next(j2);
             const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
 uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
 
 template <bool IEEE>
-static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                            const uint8_t *mult, bool alias, int variant, uint32_t *stats, WsMask mask, WsXYZ sxyz)
 {
     if (alias)
@@ -853,7 +853,7 @@ static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start,
 }
 
 template <bool IEEE>
-static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                          WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias,
                          int variant, WsMask mask)
 {
@@ -868,14 +868,14 @@ static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, c
                            accel, cid_out, count, mask);
 }
 
-void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt,
+void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz)
 {
     if (ieee) launch_density<true>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
     else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
 }
 
-void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSoA srt, WsSoA out,
+void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
                WsMask mask)
 {
@@ -903,7 +903,7 @@ void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint
     hipLaunchKernelGGL(k_gather_positions, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, out_xyz, n);
 }
 
-__global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, WsSoA srt,
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, WsSorted srt,
                                                                const float4 *__restrict__ accel, int have_step,
                                                                ws_particle80 *__restrict__ out, uint32_t n)
 {
@@ -913,8 +913,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
     const size_t id = __float_as_uint(p.w);
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_step) {
-        dp.x = srt.pred[i].w;  // density / near density ride in the sorted copy's w lanes
-        dp.y = srt.vel[i].w;
+        dp.x = srt.pred(i).w;  // density / near density ride in the sorted copy's w lanes
+        dp.y = srt.vel(i).w;
         dp.z = d.pressure_scalar * (dp.x - d.target_density);  // simulation.wgsl:192-193
         dp.w = d.near_pressure_scalar * dp.y;
         a = accel[i];
@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
     rec[4] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
-void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                           ws_particle80 *out, uint32_t n)
 {
     hipLaunchKernelGGL(k_gather_particles, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, srt, accel,
@@ -937,24 +937,21 @@ void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, c
 // ---------------------------------------------------------------------------------
 // reference-layout sort view (diagnostic, on demand; never part of ws_step)
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WS_BLOCK) k_view_keys(WsDev d, const float4 *__restrict__ pred,
-                                                        const float4 *__restrict__ pos_with_id,
+__global__ void __launch_bounds__(WS_BLOCK) k_view_keys(WsDev d, WsSorted srt,
                                                         uint32_t *__restrict__ keys_by_id, uint32_t *__restrict__ count)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= d.n) return;
-    const float4 p = pred[i];
-    const uint32_t id = __float_as_uint(pos_with_id[i].w);
+    const float4 p = srt.pred(i);
+    const uint32_t id = __float_as_uint(srt.pos[i].w);
     const uint32_t key = ref_hash_key(d, p.x, p.y, p.z);
     keys_by_id[id] = key;
     atomicAdd(&count[key], 1u);
 }
 
-void wsk_view_keys(hipStream_t s, const WsDev &d, const float4 *pred, const float4 *pos_with_id,
-                   uint32_t *keys_by_id, uint32_t *count)
+void wsk_view_keys(hipStream_t s, const WsDev &d, WsSorted srt, uint32_t *keys_by_id, uint32_t *count)
 {
-    hipLaunchKernelGGL(k_view_keys, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, pred, pos_with_id, keys_by_id,
-                       count);
+    hipLaunchKernelGGL(k_view_keys, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, srt, keys_by_id, count);
 }
 
 // stable order inside each bucket: ascending particle id
@@ -1189,7 +1186,7 @@ void wsk_pick4(hipStream_t s, const uint32_t *start, const uint32_t idx[4], uint
 }
 
 // Slab readback: owned particles (state of the last step, sorted order) with their ids.
-__global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, WsSoA srt, const float4 *__restrict__ accel,
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, WsSorted srt, const float4 *__restrict__ accel,
                                                           int have_step, ws_particle80 *__restrict__ out,
                                                           uint32_t *__restrict__ ids)
 {
@@ -1199,8 +1196,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, Ws
     const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_step) {
-        dp.x = srt.pred[i].w;
-        dp.y = srt.vel[i].w;
+        dp.x = srt.pred(i).w;
+        dp.y = srt.vel(i).w;
         dp.z = d.pressure_scalar * (dp.x - d.target_density);
         dp.w = d.near_pressure_scalar * dp.y;
         a = accel[i];
@@ -1214,7 +1211,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, Ws
     ids[k] = __float_as_uint(p.w);
 }
 
-void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSoA srt, const float4 *accel, bool have_step,
+void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids)
 {
     if (d.n == 0) return;
