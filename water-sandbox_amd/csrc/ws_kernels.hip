@@ -656,7 +656,9 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 #ifndef ND_P
 #define ND_P 64            // particles per K4 workgroup.  One wave: in the collapsing cloud neighbour counts vary
 #endif                     // 10x between tiles, and a finished wave frees its slot at once (step 60: 0.38 -> 0.29 ms)
+#ifndef ND_K
 #define ND_K 16            // list fill level that triggers a flush
+#endif
 #define ND_ROWS (ND_K + 3) // a trip of 4 candidates may start at fill level K-1
 #define ND_MASK_WORDS 64   // 2048 candidates per particle (256 B of mask rows each; only the words in use are touched)
 
