@@ -732,14 +732,13 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     uint32_t cnt = 0;
     for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
         const int cc = d.guard + c + (p - 1) * rowy;
-        uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0, b2 = 0, e2 = 0;
-        if (valid) {
-            b0 = start[cc - rowz - 1];
-            e0 = start[cc - rowz + 2];
-            b1 = start[cc - 1];
-            e1 = start[cc + 2];
-            b2 = start[cc + rowz - 1];
-            e2 = start[cc + rowz + 2];
+        // unconditional (iv is always a real particle), so the six loads go out together
+        const uint32_t b0 = start[cc - rowz - 1], b1 = start[cc - 1], b2 = start[cc + rowz - 1];
+        uint32_t e0 = start[cc - rowz + 2], e1 = start[cc + 2], e2 = start[cc + rowz + 2];
+        if (!valid) {
+            e0 = b0;
+            e1 = b1;
+            e2 = b2;
         }
         nd_run_planar(d, o, b0, e0, cnt, sxyz, push, phase2, note);
         nd_run_planar(d, o, b1, e1, cnt, sxyz, push, phase2, note);
@@ -777,43 +776,65 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     const int c = (int)cid_srt[iv];
     uint32_t total = 0;
     {
+        // unconditional loads (iv is always a real particle), six in flight per plane
         const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-            const int cc = d.guard + c + (r / 3 - 1) * rowy + (r % 3 - 1) * rowz;
-            const uint32_t b = valid ? start[cc - 1] : 0u, e = valid ? start[cc + 2] : 0u;
-            t_delta[r * NF_P + threadIdx.x] = b - total;
-            total += e - b;
-            t_end[r * NF_P + threadIdx.x] = total;
+        for (int p = 0; p < 3; p++) {
+            uint32_t b[3], e[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int cc = d.guard + c + (p - 1) * rowy + (q - 1) * rowz;
+                b[q] = start[cc - 1];
+                e[q] = start[cc + 2];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int r = 3 * p + q;
+                t_delta[r * NF_P + threadIdx.x] = b[q] - total;
+                total += e[q] - b[q];
+                t_end[r * NF_P + threadIdx.x] = total;
+            }
         }
         t_end[9 * NF_P + threadIdx.x] = 0xFFFFFFFFu;
+        if (!valid) total = 0;
     }
     if (!__ballot(total > 32u * ND_MASK_WORDS)) {
         const uint32_t *mrow = mask.words + (iv - d.base);
         const uint32_t nwords = (total + 31u) >> 5;
-        // iterator over the set bits of the mask = the neighbours in visit order
-        uint32_t word = 0, wbase = 0, widx = 0, run = 0;
+        // Iterator over the set bits of the mask = the neighbours in visit order.  `avail` holds the pending
+        // bits of the current word that belong to the current run, so the per-neighbour path is ffs + clear +
+        // add; everything rare (next word, next run, dropping the particle's own bit -- simulation.wgsl:232
+        // `particle_index == neighbour_index`) happens in advance().
+        uint32_t avail = 0, rest = 0, wbase = 0, widx = 0, run = 0;
         uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
         uint32_t end_r = t_end[threadIdx.x], delta_r = t_delta[threadIdx.x];
-        auto next = [&](uint32_t &j) -> bool {
-            for (;;) {
-                while (word == 0u) {
-                    if (widx >= nwords) return false;
-                    word = wnext;
-                    wbase = widx << 5;
-                    widx++;
-                    wnext = widx < nwords ? mrow[(size_t)widx * mask.stride] : 0u;
-                }
-                const uint32_t s = wbase + (uint32_t)__ffs((int)word) - 1u;
-                word &= word - 1u;
-                while (s >= end_r) {
-                    run++;
-                    end_r = t_end[run * NF_P + threadIdx.x];
-                    delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
-                }
-                j = s + delta_r;
-                if (j != i) return true;  // `particle_index == neighbour_index`, simulation.wgsl:232
+        const uint32_t self_s = i - t_delta[4 * NF_P + threadIdx.x];  // own candidate number (own cell = run 4)
+        auto advance = [&]() -> bool {
+            while (rest == 0u) {
+                if (widx >= nwords) return false;
+                rest = wnext;
+                wbase = widx << 5;
+                if (widx == (self_s >> 5)) rest &= ~(1u << (self_s & 31u));
+                widx++;
+                wnext = widx < nwords ? mrow[(size_t)widx * mask.stride] : 0u;
             }
+            const uint32_t s0 = wbase + (uint32_t)__ffs((int)rest) - 1u;  // lowest pending candidate number
+            while (s0 >= end_r) {
+                run++;
+                end_r = t_end[run * NF_P + threadIdx.x];
+                delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
+            }
+            const uint32_t lim = end_r - wbase;  // > s0 - wbase: the run owns at least that bit of this word
+            const uint32_t m = lim >= 32u ? 0xFFFFFFFFu : (1u << lim) - 1u;
+            avail = rest & m;
+            rest &= ~m;
+            return true;
+        };
+        auto next = [&](uint32_t &j) -> bool {
+            if (avail == 0u && !advance()) return false;
+            j = wbase + (uint32_t)__ffs((int)avail) - 1u + delta_r;
+            avail &= avail - 1u;
+            return true;
         };
         // Software pipeline: while neighbour k computes, the records of neighbour k+1 are in flight and the
         // iterator has already produced k+2.  Exhausted lanes load their own record (always a valid address).
