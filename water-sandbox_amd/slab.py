@@ -187,12 +187,19 @@ class LoopbackHub:
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
         self.hip = C.CDLL("libamdhip64.so")
-        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
 
-    def copy(self, dst, src, nbytes):
-        if nbytes and self.hip.hipMemcpy(dst, src, nbytes, 3) != 0:  # hipMemcpyDeviceToDevice
-            raise RuntimeError("hipMemcpy failed")
+    def copy(self, dst, src, nbytes, stream):
+        """Device-to-device copy ordered on the READER's stream (a blocking hipMemcpy on the null stream is ordered
+        with neither of the two non-blocking streams involved)."""
+        if nbytes and self.hip.hipMemcpyAsync(dst, src, nbytes, 3, stream) != 0:  # hipMemcpyDeviceToDevice
+            raise RuntimeError("hipMemcpyAsync failed")
+
+    def done(self, stream):
+        """The reader's copies have landed: only then may the writers reuse their send ranges."""
+        if self.hip.hipStreamSynchronize(stream) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
 
     def transport(self, rank):
         return _LoopbackTransport(self, rank)
@@ -215,7 +222,8 @@ class _LoopbackTransport(_TransportBase):
             psp, psb = hub.slots[self.rank - 1 if d == 0 else self.rank + 1]
             j = i + 1 if d == 0 else i - 1
             assert psb[j] == rb[i], "neighbour sends %d bytes, I expect %d" % (psb[j], rb[i])
-            hub.copy(rp[i], psp[j], rb[i])
+            hub.copy(rp[i], psp[j], rb[i], stream)
+        hub.done(stream)
         hub.barrier.wait()  # nobody reuses a send range before every reader is done
 
     def allgather_u32(self, values):
@@ -232,7 +240,8 @@ class _LoopbackTransport(_TransportBase):
         hub.slots[self.rank] = sp
         hub.barrier.wait()
         for r in range(self.world):
-            hub.copy(rp + r * nbytes, hub.slots[r], nbytes)
+            hub.copy(rp + r * nbytes, hub.slots[r], nbytes, stream)
+        hub.done(stream)
         hub.barrier.wait()
 
 
