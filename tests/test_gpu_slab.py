@@ -8,8 +8,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _single(ws, pos, params, steps):
-    w = ws.FluidWorker(pos, params)
+def _single(ws, pos, params, steps, ieee=False):
+    w = ws.FluidWorker(pos, params, ieee_division=ieee)
     w.run(steps)
     out = w.read_vec("particles")
     w.close()
@@ -51,5 +51,17 @@ def test_single_slab_world_of_one_equals_plain_handle(ws):
     pos = ws.cube_fluid(16, 16, 8)
     want = _single(ws, pos, params, 12)
     got, _ = ws.slab.run_loopback(pos, params, 1, 12)
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_slabs_reproduce_single_gpu_bitwise_with_ieee_division(ws):
+    """The same with WS_FLAG_IEEE_DIVISION on every handle (the flag must reach the slab kernels)."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(32768, 4321, list(params.ext_min), list(params.ext_max))
+    want = _single(ws, pos, params, 25, ieee=True)
+    got, _ = ws.slab.run_loopback(pos, params, 3, 25, ieee_division=True)
+    other = _single(ws, pos, params, 25, ieee=False)
+    assert not np.array_equal(other["acceleration"].view(np.uint32), want["acceleration"].view(np.uint32))
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f

@@ -250,7 +250,7 @@ class SlabWorker:
     """One x-slab of the domain on one GPU (ws_slab_create / ws_step / ws_slab_read_particles)."""
 
     def __init__(self, positions, ids, n_global, params, rank, world, transport, device=0, stream=None, profile=False,
-                 capacity=0, ghost_capacity=0):
+                 capacity=0, ghost_capacity=0, ieee_division=False):
         L = self._L = fluid.load_library()
         L.ws_slab_create.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(fluid.WsDeviceCfg), C.POINTER(WsTransport), C.POINTER(C.c_void_p)]
@@ -262,7 +262,7 @@ class SlabWorker:
         assert positions.shape[0] == ids.shape[0]
         cfg = fluid.WsDeviceCfg()
         cfg.device, cfg.rank, cfg.world_size = device, rank, world
-        cfg.flags = fluid.WS_FLAG_PROFILE if profile else 0
+        cfg.flags = (fluid.WS_FLAG_PROFILE if profile else 0) | (fluid.WS_FLAG_IEEE_DIVISION if ieee_division else 0)
         cfg.capacity, cfg.ghost_capacity = capacity, ghost_capacity
         cfg.stream = stream
         self.params = params
@@ -324,7 +324,7 @@ class SlabWorker:
             pass
 
 
-def run_loopback(positions, params, world, steps, device=0):
+def run_loopback(positions, params, world, steps, device=0, ieee_division=False):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
     particles of all slabs merged into original-id order.  Test helper for one-GPU boxes."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -339,7 +339,8 @@ def run_loopback(positions, params, world, steps, device=0):
     def body(r):
         try:
             sel = np.flatnonzero(owner == r).astype(np.uint32)
-            w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device)
+            w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device,
+                           ieee_division=ieee_division)
             w.run(steps)
             rec, ids = w.read()
             out[ids] = rec
