@@ -5,7 +5,8 @@ tag = sys.argv[1]; last = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 for part in "abcl":
     files = glob.glob("gpurun_out/pmc_%s_%s/*/*_counter_collection.csv" % (tag, part))
     if not files: continue
-    rows = list(csv.DictReader(open(files[0])))
+    import os
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:32]

@@ -8,7 +8,8 @@ import collections, csv, glob, json, os, sys
 cfg, dist, warm, steps, n = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def per_kernel(kind, counter):
-    f = glob.glob(os.path.join(root, "gpurun_out", "traffic_%s_%s_%s" % (cfg, dist, kind), "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(root, "gpurun_out", "traffic_%s_%s_%s" % (cfg, dist, kind), "*", "*_counter_collection.csv")),
+            key=os.path.getmtime)  # gpurun merges runs into the same directory: take the newest pass
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
