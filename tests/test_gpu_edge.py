@@ -155,6 +155,45 @@ def test_full_size_properties_c3(ws):
     w.close(); w2.close()
 
 
+def test_full_size_density_spot_check_c3(ws):
+    """BASELINE.json config 3: the densities of 256 random particles against a brute-force sum over ALL 4 194 304
+    particles (float64 numpy, no cell grid, no oracle): finds a lost or double-counted neighbour at full size."""
+    pos, params = ws.workloads.make_workload("c3", "cloud")
+    w = ws.FluidWorker(pos, params)
+    w.run(40)                      # into the collapse: the floor layer is already dense
+    before = w.read_vec("particles")
+    w.run(1)
+    after = w.read_vec("particles")
+    w.close()
+    q = before["predicted_position"][:, :3].astype(np.float64)   # the step's densities are sums over these
+    h = float(params.smoothing_radius)
+    k2 = 15.0 / (2.0 * np.pi * h ** 5)
+    k3 = 15.0 / (np.pi * h ** 6)
+    rng = np.random.default_rng(11)
+    pick = np.r_[rng.integers(0, q.shape[0], 192), np.argsort(-after["density"][:, 0])[:64]]  # random + the densest
+    for i in pick:
+        box = np.flatnonzero(np.all(np.abs(q - q[i]) <= h, axis=1))
+        dist = np.sqrt(((q[box] - q[i]) ** 2).sum(axis=1))
+        dist = dist[dist <= h]
+        rho = ((h - dist) ** 2).sum() * k2 + 1e-5
+        rho_near = ((h - dist) ** 3).sum() * k3 + 1e-5
+        assert abs(after["density"][i, 0] - rho) <= 2e-5 * rho + 1e-3, (i, after["density"][i, 0], rho, dist.size)
+        assert abs(after["density"][i, 1] - rho_near) <= 2e-5 * rho_near + 1e-3, (i, after["density"][i, 1], rho_near)
+
+
+def test_full_size_two_slabs_match_the_single_handle_c3(ws):
+    """BASELINE.json config 3 cut into two x-slabs (loopback transport, one GPU): bit-identical to the single handle."""
+    pos, params = ws.workloads.make_workload("c3", "cloud")
+    w = ws.FluidWorker(pos, params)
+    w.run(4)
+    want = w.read_vec("particles")
+    w.close()
+    got, owned = ws.slab.run_loopback(pos, params, 2, 4)
+    assert sum(owned) == pos.shape[0]
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
 def test_readback_into_an_explicitly_pinned_buffer(ws):
     """update() reads into the same host buffer every frame; the host may page-lock it (PCIe-rate copy).
     The data must not depend on the copy path."""
