@@ -155,9 +155,10 @@ def test_full_size_properties_c3(ws):
     w.close(); w2.close()
 
 
-def test_full_size_density_spot_check_c3(ws):
-    """BASELINE.json config 3: the densities of 256 random particles against a brute-force sum over ALL 4 194 304
-    particles (float64 numpy, no cell grid, no oracle): finds a lost or double-counted neighbour at full size."""
+def test_full_size_density_and_force_spot_check_c3(ws):
+    """BASELINE.json config 3: the densities (and, for half of them, the accelerations) of 256 particles against
+    brute-force sums over ALL 4 194 304 particles (float64 numpy, no cell grid, no oracle): finds a lost or
+    double-counted neighbour at full size."""
     pos, params = ws.workloads.make_workload("c3", "cloud")
     w = ws.FluidWorker(pos, params)
     w.run(40)                      # into the collapse: the floor layer is already dense
@@ -179,6 +180,30 @@ def test_full_size_density_spot_check_c3(ws):
         rho_near = ((h - dist) ** 3).sum() * k3 + 1e-5
         assert abs(after["density"][i, 0] - rho) <= 2e-5 * rho + 1e-3, (i, after["density"][i, 0], rho, dist.size)
         assert abs(after["density"][i, 1] - rho_near) <= 2e-5 * rho_near + 1e-3, (i, after["density"][i, 1], rho_near)
+    # and their accelerations (simulation.wgsl:197-269 restated in float64 over the brute-force neighbour set,
+    # with the step's own densities as inputs); the bound is relative to the sum of the term magnitudes
+    rho_all = after["density"].astype(np.float64)
+    vel = before["velocity"][:, :3].astype(np.float64)
+    ps, nps, tgt, visc = (float(params.pressure_scalar), float(params.near_pressure_scalar), float(params.target_density),
+                          float(params.viscosity_strength))
+    k2d, k3d, ksp = 15.0 / (np.pi * h ** 5), 45.0 / (np.pi * h ** 6), 315.0 / (64.0 * np.pi * h ** 9)
+    for i in pick[::2]:
+        box = np.flatnonzero(np.all(np.abs(q - q[i]) <= h, axis=1))
+        box = box[box != i]
+        off = q[box] - q[i]
+        dist = np.sqrt((off ** 2).sum(axis=1))
+        keep = dist <= h
+        box, off, dist = box[keep], off[keep], dist[keep]
+        direction = np.where(dist[:, None] > 0, off / np.maximum(dist, 1e-300)[:, None], np.array([0.0, 1.0, 0.0]))
+        p_i, pn_i = ps * (rho_all[i, 0] - tgt), nps * rho_all[i, 1]
+        p_j, pn_j = ps * (rho_all[box, 0] - tgt), nps * rho_all[box, 1]
+        press = direction * ((p_i + p_j) / 2 * (dist - h) * k2d / rho_all[box, 0])[:, None]
+        near = direction * ((pn_i + pn_j) / 2 * (dist - h) ** 2 * k3d / rho_all[box, 1])[:, None]
+        visco = (vel[box] - vel[i]) * ((h * h - dist * dist) ** 3 * ksp)[:, None]
+        acc = (press + near).sum(axis=0) / rho_all[i, 0] + visco.sum(axis=0) * visc
+        scale = (np.abs(press) + np.abs(near)).sum(axis=0) / rho_all[i, 0] + np.abs(visco).sum(axis=0) * visc
+        err = np.abs(after["acceleration"][i, :3] - acc)
+        assert np.all(err <= 3e-5 * scale + 1e-4), (i, after["acceleration"][i, :3], acc, scale, box.size)
 
 
 def test_full_size_two_slabs_match_the_single_handle_c3(ws):
