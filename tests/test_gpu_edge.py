@@ -48,6 +48,18 @@ def test_non_power_of_two_n(oracle, ws, n):
                      label="n=%d" % n)
 
 
+@pytest.mark.parametrize("size", [(2.7, 2.7, 2.7), (2.7, 2.2, 1.7)])
+def test_grids_whose_cell_count_is_not_a_multiple_of_four(oracle, ws, size):
+    """The cell scan moves 16 B per lane; the last cells of such a grid go through its scalar tail."""
+    params = ws.make_params(container_size=size)
+    pos = ws.workloads.uniform_cloud(4096, 5, list(params.ext_min), list(params.ext_max))
+    w = ws.FluidWorker(pos, params)
+    dims = w.grid_dims()
+    w.close()
+    assert (dims[0] * dims[1] * dims[2]) % 4 != 0, dims
+    _one_step_parity(oracle, ws, pos, params, label="grid %s" % (dims,))
+
+
 def test_particles_far_outside_the_grid_are_clamped_not_lost(oracle, ws):
     """Predicted positions may leave the container (position is clamped, position + v/50 is not): cells
     outside the padded dense grid are clamped; the exact distance test keeps the neighbour set."""
