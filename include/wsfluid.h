@@ -161,6 +161,10 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params);
  * label (src/fluid_compute.rs:478,:483-485): n*3 floats in ORIGINAL-ID order.
  * Waits for enqueued steps first. */
 ws_status ws_read_positions(ws_handle *h, float *out_xyz);
+/* `velocities.length()` per particle in ORIGINAL-ID order: n floats -- what the reference's (commented-out)
+ * speed colouring system reads back 80 B per particle for (src/fluid_compute.rs:489-502).  Waits for
+ * enqueued steps first. */
+ws_status ws_read_speeds(ws_handle *h, float *out_speed);
 /* Optional: page-lock a host buffer the caller owns and keeps alive -- typically the position buffer
  * update() fills every frame -- so that ws_read_positions / ws_read_particles into it run at PCIe rate
  * (no pageable staging).  The caller must ws_unpin_host_buffer it before freeing it. */

@@ -245,6 +245,8 @@ def test_readback_into_an_explicitly_pinned_buffer(ws):
             assert np.array_equal(buf, w.read_vec("particles")["position"][:, :3])
     finally:
         w.unpin_host_buffer(buf)
+    v = w.read_vec("particles")["velocity"][:, :3]
+    assert np.array_equal(w.read_speeds(), np.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2]))
     other = np.empty_like(buf)
     w.read_positions_into(other)  # a pageable buffer still works
     assert np.array_equal(other, buf)

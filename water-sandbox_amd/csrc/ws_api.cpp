@@ -691,6 +691,32 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
     return WS_OK;
 }
 
+ws_status ws_read_speeds(ws_handle *h, float *out_speed)
+{
+    if (!h || !out_speed) return WS_ERR_INVALID_ARG;
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->refmode) {
+        std::vector<ws_particle80> rec(h->n);
+        const ws_status s_ = ws_read_particles(h, rec.data());
+        if (s_) return s_;
+        for (uint32_t i = 0; i < h->n; i++) {
+            const float *v = rec[i].velocity;
+            out_speed[i] = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        }
+        return WS_OK;
+    }
+    const size_t bytes = (size_t)h->n * 4;
+    ws_status st = ensure_stage(h, bytes);
+    if (st) return st;
+    wsk_gather_speeds(h->stream, h->cur.pos, h->cur.vel, (float *)h->stage, h->n);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_speed, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_profile(h);
+    return WS_OK;
+}
+
 // Page-lock / release a host buffer the caller owns and keeps alive (e.g. the Vec update() reads positions
 // into every frame): a device->host copy into pinned memory runs at PCIe rate (C3: 0.97 ms for 50 MB) instead
 // of through the runtime's pageable staging (9.8 ms).  Explicit on purpose: pinning caller memory behind its

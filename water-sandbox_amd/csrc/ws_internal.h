@@ -179,6 +179,7 @@ void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint3
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
                WsMask mask);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
+void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                           ws_particle80 *out, uint32_t n);
 // reference-layout view

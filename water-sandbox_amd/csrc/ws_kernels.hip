@@ -926,6 +926,23 @@ void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint
     hipLaunchKernelGGL(k_gather_positions, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, out_xyz, n);
 }
 
+// `velocity.length()` per particle, the quantity of the reference's (commented-out) speed colouring,
+// src/fluid_compute.rs:489-502; same left-to-right sum as the WGSL length() restatement
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_speeds(const float4 *__restrict__ pos,
+                                                            const float4 *__restrict__ vel, float *__restrict__ out,
+                                                            uint32_t n)
+{
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = vel[i];
+    out[__float_as_uint(pos[i].w)] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+}
+
+void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n)
+{
+    hipLaunchKernelGGL(k_gather_speeds, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, vel, out, n);
+}
+
 __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, WsSorted srt,
                                                                const float4 *__restrict__ accel, int have_step,
                                                                ws_particle80 *__restrict__ out, uint32_t n)
