@@ -483,6 +483,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     if (!out) return WS_ERR_INVALID_ARG;
     *out = nullptr;
     if (!pos_xyz || n == 0) return fail(nullptr, WS_ERR_INVALID_ARG, "pos_xyz is NULL or n == 0");
+    if (n > WS_MAX_SLOTS - 16u) return fail(nullptr, WS_ERR_INVALID_ARG, "more than 2^27 particles on one device");
     ws_status st = validate_params(nullptr, params);
     if (st) return st;
     if (cfg && cfg->world_size > 1) return fail(nullptr, WS_ERR_UNSUPPORTED, "multi-GPU slabs are created with ws_create_slab");

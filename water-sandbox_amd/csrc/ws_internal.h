@@ -68,7 +68,19 @@ struct WsSorted {
     float4 *pv;   // [2j] = {pred.xyz, density after K4}, [2j + 1] = {vel.xyz, near density after K4}
     __host__ __device__ float4 &pred(uint32_t j) const { return pv[2 * (size_t)j]; }
     __host__ __device__ float4 &vel(uint32_t j) const { return pv[2 * (size_t)j + 1]; }
+    // The gathers of the force kernel's inner loop: a 32-bit byte offset from the (uniform) base lets the load
+    // take its base from scalar registers, with no 64-bit address arithmetic per neighbour.  Needs
+    // 32 * slots < 2^32, which ws_create / ws_slab_create check (WS_MAX_SLOTS).
+    __device__ const float4 &pred_near(uint32_t j) const
+    {
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pv) + j * 32u);
+    }
+    __device__ const float4 &vel_near(uint32_t j) const
+    {
+        return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pv) + j * 32u + 16u);
+    }
 };
+#define WS_MAX_SLOTS (1u << 27)
 
 struct WsXYZ {
     float *x = nullptr, *y = nullptr, *z = nullptr;

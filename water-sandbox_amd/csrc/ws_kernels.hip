@@ -675,9 +675,11 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
 {
     for (;;) {
         while (j < e && cnt < (uint32_t)ND_K) {
-            const nd_f4 X = *reinterpret_cast<const nd_f4u *>(p.x + j);
-            const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(p.y + j);
-            const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(p.z + j);
+            // 32-bit byte offsets from the three (uniform) plane bases: one shift instead of three 64-bit adds
+            const uint32_t off = j * 4u;
+            const nd_f4 X = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.x) + off);
+            const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.y) + off);
+            const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.z) + off);
             __builtin_amdgcn_sched_barrier(0);  // the three loads are issued before any is consumed
             const nd_f4 ex = X - o.x, ey = Y - o.y, ez = Z - o.z;
             const nd_f4 d2 = ex * ex + ey * ey + ez * ez;
@@ -840,12 +842,12 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         // iterator has already produced k+2.  Exhausted lanes load their own record (always a valid address).
         uint32_t j1 = iv, j2 = iv;
         bool have0 = next(j1);
-        float4 q_next = srt.pred(have0 ? j1 : iv), nvel_next = srt.vel(have0 ? j1 : iv);
+        float4 q_next = srt.pred_near(have0 ? j1 : iv), nvel_next = srt.vel_near(have0 ? j1 : iv);
         bool have1 = have0 && next(j2);
         while (have0) {
             const float4 q = q_next, nvel = nvel_next;
-            q_next = srt.pred(have1 ? j2 : iv);
-            nvel_next = srt.vel(have1 ? j2 : iv);
+            q_next = srt.pred_near(have1 ? j2 : iv);
+            nvel_next = srt.vel_near(have1 ? j2 : iv);
             have0 = have1;
             have1 = have1 && next(j2);
             const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
