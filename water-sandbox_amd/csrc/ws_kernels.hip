@@ -839,15 +839,15 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
             return true;
         };
         // Software pipeline: while neighbour k computes, the records of neighbour k+1 are in flight and the
-        // iterator has already produced k+2.  Exhausted lanes load their own record (always a valid address).
-        uint32_t j1 = iv, j2 = iv;
+        // iterator has already produced k+2.
+        uint32_t j1 = iv, j2 = iv;  // next() leaves j alone when it fails: an exhausted lane keeps re-loading a valid record
         bool have0 = next(j1);
-        float4 q_next = srt.pred_near(have0 ? j1 : iv), nvel_next = srt.vel_near(have0 ? j1 : iv);
+        float4 q_next = srt.pred_near(j1), nvel_next = srt.vel_near(j1);
         bool have1 = have0 && next(j2);
         while (have0) {
             const float4 q = q_next, nvel = nvel_next;
-            q_next = srt.pred_near(have1 ? j2 : iv);
-            nvel_next = srt.vel_near(have1 ? j2 : iv);
+            q_next = srt.pred_near(j2);
+            nvel_next = srt.vel_near(j2);
             have0 = have1;
             have1 = have1 && next(j2);
             const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
