@@ -107,6 +107,8 @@ def main():
     distributed = world > 1 or os.environ.get("WS_BENCH_FORCE_SLAB") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("WS_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank %= torch.cuda.device_count()  # the gloo rehearsal: several ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
 
     if distributed:
@@ -117,7 +119,13 @@ def main():
 
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
             os.environ.setdefault(k, v)  # the one-rank rehearsal (WS_BENCH_FORCE_SLAB=1) without a launcher
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # WS_BENCH_BACKEND=gloo: rehearsal of the multi-rank path with several ranks on ONE GPU (RCCL refuses two
+        # ranks per device); the device buffers then travel through host memory, so the numbers mean nothing
+        backend = os.environ.get("WS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         ctrl = dist.new_group(backend="gloo")
         # the library enqueues on the stream RCCL's point-to-point calls are ordered on: an explicit,
         # non-default torch stream made current for the whole run (the default stream's handle is 0,

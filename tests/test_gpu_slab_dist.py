@@ -33,3 +33,23 @@ def test_two_process_slabs_match_single_handle_bitwise(ws, tmp_path):
     assert np.all(seen == 1)
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_bench_multi_rank_path_rehearsal(tmp_path):
+    """bench.py's --gpus N branch (launcher env, slab workload, transport, max-over-ranks timing, one JSON line
+    from rank 0), rehearsed with two gloo ranks on the one GPU; RCCL itself needs one GPU per rank."""
+    import json
+
+    env = dict(os.environ, WS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--config", "c1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["unit"] == "steps/s" and line["value"] > 0 and line["config"]["particles"] == 2 * 4096
+    assert abs(line["value"] - 2 * line["global_steps_per_s"]) < 1e-9 * line["value"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
