@@ -161,6 +161,13 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params);
  * label (src/fluid_compute.rs:478,:483-485): n*3 floats in ORIGINAL-ID order.
  * Waits for enqueued steps first. */
 ws_status ws_read_positions(ws_handle *h, float *out_xyz);
+/* The same readback split in two for a frame loop that overlaps it with the next step (SURVEY 8(b) "pipelining
+ * contract"): _begin captures the positions as of the steps enqueued so far and starts the copy into out_xyz
+ * (page-lock it: ws_pin_host_buffer) on a separate stream and returns; ws_step calls made after it run while
+ * the copy is in flight; _end waits for the copy.  One readback in flight per handle; out_xyz must stay valid
+ * until _end. */
+ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz);
+ws_status ws_read_positions_end(ws_handle *h);
 /* `velocities.length()` per particle in ORIGINAL-ID order: n floats -- what the reference's (commented-out)
  * speed colouring system reads back 80 B per particle for (src/fluid_compute.rs:489-502).  Waits for
  * enqueued steps first. */

@@ -231,6 +231,30 @@ def test_full_size_two_slabs_match_the_single_handle_c3(ws):
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
+def test_asynchronous_readback_captures_the_state_at_begin(ws):
+    """update() of frame f draws the step submitted in frame f-1 while frame f's step already runs: `begin` must
+    capture the positions as of the steps enqueued before it, whatever is enqueued afterwards."""
+    pos, params = ws.workloads.make_workload("c2", "cloud")
+    w = ws.FluidWorker(pos, params)
+    buf = np.empty((pos.shape[0], 3), np.float32)
+    w.pin_host_buffer(buf)
+    try:
+        w.run(3)
+        want = w.read_positions()
+        w.read_positions_begin(buf)
+        with pytest.raises(ws.WsError):
+            w.read_positions_begin(buf)          # one in flight
+        w.run(5)                                 # overlaps with the copy
+        w.read_positions_end()
+        assert np.array_equal(buf, want)
+        assert not np.array_equal(w.read_positions(), want)
+        with pytest.raises(ws.WsError):
+            w.read_positions_end()               # nothing in flight
+    finally:
+        w.unpin_host_buffer(buf)
+    w.close()
+
+
 def test_readback_into_an_explicitly_pinned_buffer(ws):
     """update() reads into the same host buffer every frame; the host may page-lock it (PCIe-rate copy).
     The data must not depend on the copy path."""

@@ -353,6 +353,13 @@ ws_status upload_positions(ws_handle *h, const float *pos_xyz)
 void free_all(ws_handle *h)
 {
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->copy_stream) {
+        hipStreamSynchronize(h->copy_stream);
+        hipStreamDestroy(h->copy_stream);
+    }
+    if (h->rb_gathered) hipEventDestroy(h->rb_gathered);
+    if (h->rb_done) hipEventDestroy(h->rb_done);
+    hipFree(h->rb_stage);
     drain_profile(h);
     for (auto e : h->pool) hipEventDestroy(e);
     free_grid(h);
@@ -689,6 +696,48 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
     HIP_TRY(h, hipMemcpyAsync(out_xyz, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_profile(h);
+    return WS_OK;
+}
+
+// The frame loop's readback, overlapped with the next step: `begin` enqueues the id-order gather behind the steps
+// enqueued so far (a ~20 us kernel on the library's stream) and starts the device->host copy on a separate copy
+// stream; steps enqueued after `begin` run while the copy is in flight; `end` waits for the copy alone.
+ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
+{
+    if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
+    if (h->slab || h->refmode) return fail(h, WS_ERR_UNSUPPORTED, "asynchronous readback needs a plain single-GPU handle");
+    if (h->rb_inflight) return fail(h, WS_ERR_INVALID_ARG, "a readback is already in flight (call ws_read_positions_end)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n * 12;
+    if (!h->copy_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->rb_gathered, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->rb_done, hipEventDisableTiming));
+    }
+    if (h->rb_bytes < bytes) {
+        hipFree(h->rb_stage);
+        h->rb_stage = nullptr;
+        h->rb_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->rb_stage, bytes));
+        h->rb_bytes = bytes;
+    }
+    wsk_gather_positions(h->stream, h->cur.pos, h->rb_stage, h->n);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->rb_gathered, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->rb_gathered, 0));
+    HIP_TRY(h, hipMemcpyAsync(out_xyz, h->rb_stage, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(h, hipEventRecord(h->rb_done, h->copy_stream));
+    h->rb_inflight = true;
+    return WS_OK;
+}
+
+ws_status ws_read_positions_end(ws_handle *h)
+{
+    if (!h) return WS_ERR_INVALID_ARG;
+    if (!h->rb_inflight) return fail(h, WS_ERR_INVALID_ARG, "no readback in flight");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(h->rb_done));
+    h->rb_inflight = false;
     return WS_OK;
 }
 

@@ -129,6 +129,12 @@ struct ws_handle {
     // staging for uploads / readback
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    // asynchronous position readback (ws_read_positions_begin / _end): own staging, own copy stream
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t rb_gathered = nullptr, rb_done = nullptr;
+    float *rb_stage = nullptr;
+    size_t rb_bytes = 0;
+    bool rb_inflight = false;
 
     // reference-layout sort view (lazy)
     uint32_t *v_keys = nullptr, *v_perm = nullptr, *v_tmp = nullptr, *v_count = nullptr,

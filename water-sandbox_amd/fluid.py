@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "ws_default_params", "ws_get_smoothing_kernel", "ws_cube_fluid", "ws_get_ext",
     "ws_bit_sorter_stage_count", "ws_status_string", "ws_abi_version", "ws_create", "ws_destroy",
     "ws_step", "ws_ready", "ws_sync", "ws_set_params", "ws_read_positions", "ws_read_particles",
-    "ws_reset", "ws_write_particles", "ws_pin_host_buffer", "ws_unpin_host_buffer", "ws_read_speeds", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
+    "ws_reset", "ws_write_particles", "ws_pin_host_buffer", "ws_unpin_host_buffer", "ws_read_speeds", "ws_read_positions_begin", "ws_read_positions_end", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
     "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
     "ws_grid_dims", "ws_read_stats", "ws_slab_assign", "ws_slab_create", "ws_slab_read_particles",
 ]
@@ -123,6 +123,8 @@ def load_library():
     L.ws_reset.argtypes = [vp, vp]
     L.ws_pin_host_buffer.argtypes = [vp, vp, C.c_uint64]
     L.ws_read_speeds.argtypes = [vp, vp]
+    L.ws_read_positions_begin.argtypes = [vp, vp]
+    L.ws_read_positions_end.argtypes = [vp]
     L.ws_unpin_host_buffer.argtypes = [vp, vp]
     L.ws_write_particles.argtypes = [vp, vp]
     L.ws_read_sort_view.argtypes = [vp, vp, vp, vp]
@@ -254,6 +256,15 @@ class FluidWorker:
         out = np.empty((self.n, 3), np.float32)
         self._check(self._L.ws_read_positions(self._h, out.ctypes.data))
         return out
+
+    def read_positions_begin(self, buf):
+        """Start an asynchronous id-order position readback into `buf` ((n, 3) float32, ideally pinned); steps
+        enqueued afterwards overlap with the copy.  Finish with read_positions_end()."""
+        assert buf.dtype == np.float32 and buf.shape == (self.n, 3) and buf.flags.c_contiguous
+        self._check(self._L.ws_read_positions_begin(self._h, buf.ctypes.data))
+
+    def read_positions_end(self):
+        self._check(self._L.ws_read_positions_end(self._h))
 
     def read_speeds(self):
         """|velocity| per particle in original-id order (the reference's speed colouring input)."""
