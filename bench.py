@@ -40,7 +40,8 @@ def parse_args():
     ap.add_argument("--config", default="c3", help="c1..c5 | ref (BASELINE.md section 2)")
     ap.add_argument("--dist", default="cloud", choices=["cloud", "lattice"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=12,
+                    help="oracle steps timed for cpu_baseline (~10 s of CPU work at C3 on 16 threads)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel table to stderr")
     return ap.parse_args()
 
