@@ -345,7 +345,12 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     const uint32_t c = cid_cur[i];
     const uint32_t b = start[d.guard + c], e = start[d.guard + c + 1];
     uint32_t rank = 0;
-    for (uint32_t t = b; t < e; t++) rank += (id_tmp[t] < id) ? 1u : 0u;
+    for (uint32_t t = b; t < e; t += 4) {  // four cell-mates per trip: their loads go out together
+        const uint32_t a0 = id_tmp[t], a1 = id_tmp[min(t + 1u, e - 1u)], a2 = id_tmp[min(t + 2u, e - 1u)],
+                       a3 = id_tmp[min(t + 3u, e - 1u)];
+        rank += (a0 < id ? 1u : 0u) + ((t + 1u < e && a1 < id) ? 1u : 0u) + ((t + 2u < e && a2 < id) ? 1u : 0u) +
+                ((t + 3u < e && a3 < id) ? 1u : 0u);
+    }
     const uint32_t dst = b + rank;
     const float4 q = cur.pred[i];
     srt.pos[dst] = cur.pos[i];
