@@ -278,11 +278,12 @@ void enqueue_step(ws_handle *h)
     hipStream_t s = h->stream;
     {
         Prof p(h, WS_K_SCAN);
-        wsk_scan(s, h->count, h->start + d.guard, h->cursor, h->bsum, &h->scan_launches, d.ncells, true, 0);
+        // no fill cursors: particles are placed by the ranks they drew when they were binned
+        wsk_scan(s, h->count, h->start + d.guard, nullptr, h->bsum, &h->scan_launches, d.ncells, true, 0);
     }
     {
         Prof p(h, WS_K_SCATTER);
-        wsk_scatter(s, h->cid_cur, h->cur.pos, h->cursor, h->slot_tmp, h->id_tmp, d.n);
+        wsk_place(s, d, h->cid_cur, h->cur.rank, h->cur.pos, h->start, h->slot_tmp, h->id_tmp);
     }
     {
         Prof p(h, WS_K_REORDER);
@@ -328,7 +329,7 @@ ws_status bin_current(ws_handle *h)
     HIP_TRY(h, hipMemsetAsync(h->count, 0, (size_t)h->dev.ncells * 4, h->stream));
     {
         Prof pr(h, WS_K_BIN);
-        wsk_bin(h->stream, h->dev, h->cur.pred, h->cid_cur, h->count);
+        wsk_bin(h->stream, h->dev, h->cur.pred, h->cid_cur, h->count, h->cur.rank);
     }
     HIP_TRY(h, hipGetLastError());
     return WS_OK;
@@ -363,7 +364,7 @@ void free_all(ws_handle *h)
     drain_profile(h);
     for (auto e : h->pool) hipEventDestroy(e);
     free_grid(h);
-    hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred);
+    hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred); hipFree(h->cur.rank);
     hipFree(h->srt.pos); hipFree(h->srt.pv);
     hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
@@ -552,6 +553,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->cur.pos, n16));
     CREATE_HIP(hipMalloc(&h->cur.vel, n16));
     CREATE_HIP(hipMalloc(&h->cur.pred, n16));
+    CREATE_HIP(hipMalloc(&h->cur.rank, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->srt.pos, n16));
     CREATE_HIP(hipMalloc(&h->srt.pv, 2 * n16));
     CREATE_HIP(hipMalloc(&h->sxyz.x, n16 / 4)); CREATE_HIP(hipMalloc(&h->sxyz.y, n16 / 4)); CREATE_HIP(hipMalloc(&h->sxyz.z, n16 / 4));

@@ -47,6 +47,9 @@ struct WsSoA {
     float4 *pos;   // xyz = position, w = particle id (bits)
     float4 *vel;   // xyz = velocity (sorted copy: w = near density after K4)
     float4 *pred;  // xyz = predicted_position (sorted copy: w = density after K4)
+    // Optional (single-GPU handles): the particle's arrival rank inside its cell, as returned by the histogram's
+    // atomic when the particle was binned.  With it the sort places particles without a second round of atomics.
+    uint32_t *rank;
 };
 
 // Reference-order mode (WS_FLAG_REFERENCE_ORDER): the reference's own buffer set, by particle id
@@ -181,7 +184,9 @@ struct WsSlab {
 // ---- kernel launchers (ws_kernels.hip) -------------------------------------------
 void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32_t n);
 void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);
-void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count);
+void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count, uint32_t *rank);
+void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const float4 *pos_with_id,
+               const uint32_t *start, uint32_t *slot_tmp, uint32_t *id_tmp);
 void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t *launches,
               uint32_t nitems, bool zero_count, uint32_t base);
 uint32_t wsk_scan_state_words(uint32_t nitems);

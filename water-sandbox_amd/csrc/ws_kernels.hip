@@ -101,19 +101,21 @@ void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur,
 // K1': cell binning (stand-alone form; the steady-state form is fused into k_force)
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WS_BLOCK) k_bin(WsDev d, const float4 *__restrict__ pred,
-                                                  uint32_t *__restrict__ cid, uint32_t *__restrict__ count)
+                                                  uint32_t *__restrict__ cid, uint32_t *__restrict__ count,
+                                                  uint32_t *__restrict__ rank)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= d.n) return;
     const float4 p = pred[i];
     const uint32_t c = grid_cell(d, p.x, p.y, p.z);
     cid[i] = c;
-    atomicAdd(&count[c], 1u);
+    const uint32_t r = atomicAdd(&count[c], 1u);
+    if (rank) rank[i] = r;
 }
 
-void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count)
+void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count, uint32_t *rank)
 {
-    hipLaunchKernelGGL(k_bin, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, pred, cid, count);
+    hipLaunchKernelGGL(k_bin, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, pred, cid, count, rank);
 }
 
 // ---------------------------------------------------------------------------------
@@ -270,13 +272,13 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count,
         r.w = r.z + v[q].z;
         if (at + 4u <= nitems) {
             *reinterpret_cast<uint4 *>(start + at) = r;
-            *reinterpret_cast<uint4 *>(cursor + at) = r;
+            if (cursor) *reinterpret_cast<uint4 *>(cursor + at) = r;
             if (ZERO) *reinterpret_cast<uint4 *>(count + at) = make_uint4(0u, 0u, 0u, 0u);
         } else {
             const uint32_t rr[3] = {r.x, r.y, r.z};
             for (uint32_t k = 0; k < 3u && at + k < nitems; k++) {
                 start[at + k] = rr[k];
-                cursor[at + k] = rr[k];
+                if (cursor) cursor[at + k] = rr[k];
                 if (ZERO) count[at + k] = 0u;
             }
         }
@@ -320,6 +322,28 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict
     if (!active) return;
     slot_tmp[slot] = i;
     if (id_tmp) id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
+}
+
+// The same placement from ranks taken when the particles were binned (the force kernel's epilogue or k_bin):
+// slot = cell start + rank, no atomics.  Single-GPU handles; a slab's migration leaves holes in the ranks.
+__global__ void __launch_bounds__(WS_BLOCK) k_place(WsDev d, const uint32_t *__restrict__ cid,
+                                                    const uint32_t *__restrict__ rank,
+                                                    const float4 *__restrict__ pos_with_id,
+                                                    const uint32_t *__restrict__ start, uint32_t *__restrict__ slot_tmp,
+                                                    uint32_t *__restrict__ id_tmp)
+{
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= d.n) return;
+    const uint32_t slot = start[d.guard + cid[i]] + rank[i];
+    slot_tmp[slot] = i;
+    id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
+}
+
+void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const float4 *pos_with_id,
+               const uint32_t *start, uint32_t *slot_tmp, uint32_t *id_tmp)
+{
+    hipLaunchKernelGGL(k_place, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cid, rank, pos_with_id, start, slot_tmp,
+                       id_tmp);
 }
 
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
@@ -548,7 +572,8 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
     // next step's hash_particles (simulation.wgsl:130-141) on the dense grid
     const uint32_t nc = grid_cell(d, qx, qy, qz);
     cid_out[i] = nc;
-    wave_run_atomic_inc(count, nc, true);  // one atomic per run of lanes that moved into the same cell
+    const uint32_t r = wave_run_atomic_inc(count, nc, true);  // one atomic per run of lanes that moved into the same cell
+    if (out.rank) out.rank[i] = r;  // arrival rank inside the cell: the sort's tentative slot, without more atomics
 }
 
 // ---------------------------------------------------------------------------------
