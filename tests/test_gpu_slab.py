@@ -65,3 +65,14 @@ def test_slabs_reproduce_single_gpu_bitwise_with_ieee_division(ws):
     assert not np.array_equal(other["acceleration"].view(np.uint32), want["acceleration"].view(np.uint32))
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_slabs_without_halo_overlap_give_the_same_bits(ws, monkeypatch):
+    """WS_SLAB_OVERLAP=0 keeps halos and kernels on one stream (no early / late split); same result."""
+    monkeypatch.setenv("WS_SLAB_OVERLAP", "0")
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(32768, 99, list(params.ext_min), list(params.ext_max))
+    want = _single(ws, pos, params, 25)
+    got, _ = ws.slab.run_loopback(pos, params, 3, 25)
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f

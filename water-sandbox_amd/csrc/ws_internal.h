@@ -176,6 +176,10 @@ struct WsSlab {
     uint32_t *host_pin = nullptr;     // pinned: migration matrix [W*W], then the boundary table [4W]
     hipEvent_t ev_mark = nullptr, ev_bnd = nullptr;  // their copies have landed
     bool mark_pending = false;        // slab_mark already enqueued for the next step
+    // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute
+    hipStream_t comm = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr;
+    bool overlap = true;              // WS_SLAB_OVERLAP=0 keeps everything on one stream
     uint32_t gL = 0, gR = 0;          // ghosts currently staged in front of / behind the owned range
     // cumulative statistics
     uint64_t migrated_out = 0, ghosts_in = 0;

@@ -12,6 +12,7 @@ Transports:
                       device-to-device copies.  Lets the one-GPU test box exercise the whole slab
                       protocol (ghost indexing, migration, bit-exactness against one GPU).
 """
+import contextlib
 import ctypes as C
 import threading
 
@@ -97,10 +98,21 @@ class TorchDistTransport(_TransportBase):
         self.data_group, self.ctrl_group = data_group, ctrl_group
         # RCCL ("nccl") calls are ordered on the current stream; gloo (tests) is not: fence by hand
         self.stream_ordered = dist.get_backend(data_group) == "nccl"
+        self._ext = {}
 
     def _fence(self):
         if not self.stream_ordered:
             self.torch.cuda.synchronize(self.device)
+
+    def _on(self, stream):
+        """Context in which torch's current stream is the HIP stream the library names: RCCL calls are ordered on
+        the current stream, and the library issues its halos on a second stream while the first one computes."""
+        if not (self.stream_ordered and stream):
+            return contextlib.nullcontext()
+        ext = self._ext.get(stream)
+        if ext is None:
+            ext = self._ext[stream] = self.torch.cuda.ExternalStream(stream, device=self.device)
+        return self.torch.cuda.stream(ext)
 
     def _tensor(self, ptr, nbytes):
         return self.torch.as_tensor(_DevMem(ptr, nbytes), device=self.device)
@@ -118,8 +130,9 @@ class TorchDistTransport(_TransportBase):
                 ops.append(dist.P2POp(dist.irecv, t, peer, group=self.data_group))
         if ops:
             self._fence()
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()  # stream-ordered on the current stream for the nccl backend
+            with self._on(stream):
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()  # stream-ordered on the current stream for the nccl backend
             self._fence()
 
     def allgather_u32(self, values):
@@ -132,7 +145,8 @@ class TorchDistTransport(_TransportBase):
         src = self._tensor(sp, nbytes)
         dst = self._tensor(rp, nbytes * self.world)
         if self.stream_ordered:
-            self.dist.all_gather_into_tensor(dst, src, group=self.data_group)
+            with self._on(stream):
+                self.dist.all_gather_into_tensor(dst, src, group=self.data_group)
         else:  # gloo (tests): list form, fenced
             self._fence()
             self.dist.all_gather(list(dst.view(self.world, nbytes).unbind(0)), src, group=self.data_group)
