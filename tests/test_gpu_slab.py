@@ -67,6 +67,19 @@ def test_slabs_reproduce_single_gpu_bitwise_with_ieee_division(ws):
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_slabs_with_halo_overlap_give_the_same_bits(ws, monkeypatch, world):
+    """WS_SLAB_OVERLAP=1: halos on a second stream, K4 / K5 split into an early range and the late boundary layers."""
+    monkeypatch.setenv("WS_SLAB_OVERLAP", "1")
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
+    want = _single(ws, pos, params, 40)
+    got, owned = ws.slab.run_loopback(pos, params, world, 40)
+    assert sum(owned) == pos.shape[0]
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
 def test_slabs_without_halo_overlap_give_the_same_bits(ws, monkeypatch):
     """WS_SLAB_OVERLAP=0 keeps halos and kernels on one stream (no early / late split); same result."""
     monkeypatch.setenv("WS_SLAB_OVERLAP", "0")

@@ -10,9 +10,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_process_slabs_match_single_handle_bitwise(ws, tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_two_process_slabs_match_single_handle_bitwise(ws, tmp_path, overlap):
     steps = 30
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               WS_SLAB_OVERLAP=overlap)
     pattern = str(tmp_path / "slab_%d.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "tests", "dist_slab_worker.py"), pattern, str(steps)]

@@ -179,7 +179,7 @@ struct WsSlab {
     // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute
     hipStream_t comm = nullptr;
     hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr;
-    bool overlap = true;              // WS_SLAB_OVERLAP=0 keeps everything on one stream
+    bool overlap = false;             // WS_SLAB_OVERLAP=1 turns it on (off until it has been measured on a multi-GPU node)
     uint32_t gL = 0, gR = 0;          // ghosts currently staged in front of / behind the owned range
     // cumulative statistics
     uint64_t migrated_out = 0, ghosts_in = 0;
