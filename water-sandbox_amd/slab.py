@@ -107,8 +107,8 @@ class TorchDistTransport(_TransportBase):
     def _on(self, stream):
         """Context in which torch's current stream is the HIP stream the library names: RCCL calls are ordered on
         the current stream, and the library issues its halos on a second stream while the first one computes."""
-        if not (self.stream_ordered and stream):
-            return contextlib.nullcontext()
+        if not (self.stream_ordered and stream) or stream == self.torch.cuda.current_stream(self.device).cuda_stream:
+            return contextlib.nullcontext()  # gloo (fenced by hand), or already the current stream
         ext = self._ext.get(stream)
         if ext is None:
             ext = self._ext[stream] = self.torch.cuda.ExternalStream(stream, device=self.device)
