@@ -99,6 +99,8 @@ class TorchDistTransport(_TransportBase):
         # RCCL ("nccl") calls are ordered on the current stream; gloo (tests) is not: fence by hand
         self.stream_ordered = dist.get_backend(data_group) == "nccl"
         self._ext = {}
+        # torch's current stream when the transport was made: the stream the handle is created on
+        self._home_stream = torch.cuda.current_stream(self.device).cuda_stream if torch.cuda.is_available() else 0
 
     def _fence(self):
         if not self.stream_ordered:
@@ -107,7 +109,7 @@ class TorchDistTransport(_TransportBase):
     def _on(self, stream):
         """Context in which torch's current stream is the HIP stream the library names: RCCL calls are ordered on
         the current stream, and the library issues its halos on a second stream while the first one computes."""
-        if not (self.stream_ordered and stream) or stream == self.torch.cuda.current_stream(self.device).cuda_stream:
+        if not (self.stream_ordered and stream) or stream == self._home_stream:
             return contextlib.nullcontext()  # gloo (fenced by hand), or already the current stream
         ext = self._ext.get(stream)
         if ext is None:
