@@ -133,7 +133,13 @@ def main():
         # which ws_device_cfg.stream reads as "create your own")
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
         pos, ids, n_global, params = ws.slab.make_dist_workload(ws, args.config, args.dist, rank, world)
-        transport = ws.slab.TorchDistTransport(rank, world, local_rank, data_group=None, ctrl_group=ctrl)
+        if os.environ.get("WS_TRANSPORT", "torch") == "rccl":
+            # the library's own RCCL transport: torch.distributed only carries rank 0's unique id to the others
+            box = [ws.slab.NativeRcclTransport.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=ctrl)
+            transport = ws.slab.NativeRcclTransport(box[0], rank, world, local_rank)
+        else:
+            transport = ws.slab.TorchDistTransport(rank, world, local_rank, data_group=None, ctrl_group=ctrl)
         worker = ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
                                     stream=torch.cuda.current_stream().cuda_stream, profile=True)
         n_rank = n_global // world  # particles per rank at t = 0 (the single-GPU config's count)

@@ -216,6 +216,18 @@ typedef struct ws_transport {
     int (*allgather_dev)(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream);
 } ws_transport;
 
+/* A ws_transport implemented inside the library with RCCL (ncclSend / ncclRecv groups with the two x-neighbours,
+ * ncclAllGather for the count words), for hosts that have no communication layer of their own.  librccl is loaded
+ * at run time.  Rank 0 draws a unique id and the host hands its 128 bytes to every rank (any out-of-band channel);
+ * every rank then creates its transport -- a collective call -- on the device its slab will live on.  The
+ * transport must outlive the slab handle created with it. */
+#define WS_RCCL_UNIQUE_ID_BYTES 128
+ws_status ws_rccl_unique_id(void *out128);
+ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_t world_size, int32_t device,
+                                   ws_transport *out);
+void ws_rccl_transport_destroy(ws_transport *t);
+const char *ws_rccl_last_error(void);
+
 /* Host-only: which slab owns each position (by the x cell of floor(x / h) in the global grid, equal
  * cell-count cuts S_r = r * nx / world_size).  out_rank holds n entries. */
 ws_status ws_slab_assign(const ws_params *params, const float *pos_xyz, uint32_t n, uint32_t world_size,

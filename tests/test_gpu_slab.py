@@ -89,3 +89,22 @@ def test_slabs_without_halo_overlap_give_the_same_bits(ws, monkeypatch):
     got, _ = ws.slab.run_loopback(pos, params, 3, 25)
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_native_rccl_transport_single_rank(ws):
+    """The library's own RCCL transport (communicator of one rank: the collectives run, there are no neighbours):
+    a slab handle driven through it reproduces the plain handle bit for bit."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0))
+    pos = ws.workloads.uniform_cloud(32768, 7, list(params.ext_min), list(params.ext_max))
+    want = _single(ws, pos, params, 12)
+    tr = ws.slab.NativeRcclTransport(ws.slab.NativeRcclTransport.unique_id(), 0, 1, 0)
+    ids = np.arange(pos.shape[0], dtype=np.uint32)
+    w = ws.slab.SlabWorker(pos, ids, pos.shape[0], params, 0, 1, tr)
+    w.run(12)
+    rec, got_ids = w.read()
+    w.close()
+    tr.close()
+    got = np.zeros_like(want)
+    got[got_ids] = rec
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f

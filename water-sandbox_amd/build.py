@@ -7,7 +7,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwsfluid.so")
 
-SOURCES = ["ws_kernels.hip", "ws_api.cpp"]
+SOURCES = ["ws_kernels.hip", "ws_api.cpp", "ws_rccl.cpp"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
 
 # -ffp-contract=off: every float op in the kernels is one IEEE binary32 op, written in the
@@ -39,7 +39,7 @@ def build_library(force=False, verbose=False):
         return LIB
     cmd = [hipcc()] + HIPCC_FLAGS + [
         "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB,
-    ] + [os.path.join(CSRC, s) for s in SOURCES]
+    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,161 @@
+// ws_rccl.cpp -- a ws_transport made of RCCL calls issued by the library itself (no host-language callbacks in
+// the step): ncclSend / ncclRecv groups with the two x-neighbours over xGMI, ncclAllGather for the few count words.
+// RCCL is loaded at run time (dlopen), so the library has no link-time dependency on it and single-GPU use
+// never touches it.  The host distributes rank 0's unique id (128 bytes) by whatever means it has.
+#include "wsfluid.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+namespace {
+
+struct NcclUniqueId {
+    char internal[WS_RCCL_UNIQUE_ID_BYTES];
+};
+typedef void *NcclComm;
+enum { NCCL_UINT8 = 1 };
+
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+    int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+};
+
+RcclApi g_api;
+std::once_flag g_once;
+
+template <class F>
+bool sym(F &fn, const char *name)
+{
+    fn = reinterpret_cast<F>(dlsym(g_api.lib, name));
+    if (!fn) g_api.error = std::string("librccl: missing symbol ") + name;
+    return fn != nullptr;
+}
+
+bool load_rccl()
+{
+    std::call_once(g_once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_api.lib) break;
+        }
+        if (!g_api.lib) {
+            g_api.error = std::string("cannot load librccl: ") + dlerror();
+            return;
+        }
+        const bool ok = sym(g_api.GetUniqueId, "ncclGetUniqueId") && sym(g_api.CommInitRank, "ncclCommInitRank") &&
+                        sym(g_api.CommDestroy, "ncclCommDestroy") && sym(g_api.GroupStart, "ncclGroupStart") &&
+                        sym(g_api.GroupEnd, "ncclGroupEnd") && sym(g_api.Send, "ncclSend") && sym(g_api.Recv, "ncclRecv") &&
+                        sym(g_api.AllGather, "ncclAllGather") && sym(g_api.GetErrorString, "ncclGetErrorString");
+        if (!ok) {
+            dlclose(g_api.lib);
+            g_api.lib = nullptr;
+        }
+    });
+    return g_api.lib != nullptr;
+}
+
+struct RcclTransport {
+    NcclComm comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    std::string error;
+};
+
+int check(RcclTransport *t, int rc, const char *what)
+{
+    if (rc == 0) return 0;
+    t->error = std::string(what) + ": " + g_api.GetErrorString(rc);
+    fprintf(stderr, "wsfluid rccl transport (rank %d): %s\n", t->rank, t->error.c_str());
+    return 1;
+}
+
+// ws_transport::sendrecv: segment k, direction d (0 = rank - 1, 1 = rank + 1) at index 2k + d; one RCCL group
+int rccl_sendrecv(void *ctx, uint32_t nseg, void *const send_ptr[], const uint64_t send_bytes[], void *const recv_ptr[],
+                  const uint64_t recv_bytes[], void *stream)
+{
+    RcclTransport *t = static_cast<RcclTransport *>(ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bool any = false;
+    for (uint32_t i = 0; i < 2 * nseg; i++) any = any || send_bytes[i] || recv_bytes[i];
+    if (!any) return 0;
+    if (check(t, g_api.GroupStart(), "ncclGroupStart")) return 1;
+    int rc = 0;
+    for (uint32_t i = 0; i < 2 * nseg && !rc; i++) {
+        const int peer = (i % 2 == 0) ? t->rank - 1 : t->rank + 1;
+        if (send_bytes[i]) rc = g_api.Send(send_ptr[i], (size_t)send_bytes[i], NCCL_UINT8, peer, t->comm, s);
+        if (!rc && recv_bytes[i]) rc = g_api.Recv(recv_ptr[i], (size_t)recv_bytes[i], NCCL_UINT8, peer, t->comm, s);
+    }
+    const int rc_end = g_api.GroupEnd();
+    if (check(t, rc, "ncclSend/ncclRecv")) return 1;
+    return check(t, rc_end, "ncclGroupEnd");
+}
+
+int rccl_allgather(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream)
+{
+    RcclTransport *t = static_cast<RcclTransport *>(ctx);
+    return check(t, g_api.AllGather(send_ptr, recv_ptr, (size_t)bytes_each, NCCL_UINT8, t->comm, static_cast<hipStream_t>(stream)),
+                 "ncclAllGather");
+}
+
+}  // namespace
+
+extern "C" {
+
+ws_status ws_rccl_unique_id(void *out128)
+{
+    if (!out128) return WS_ERR_INVALID_ARG;
+    if (!load_rccl()) return WS_ERR_COMM;
+    NcclUniqueId id;
+    if (g_api.GetUniqueId(&id) != 0) return WS_ERR_COMM;
+    memcpy(out128, id.internal, sizeof id.internal);
+    return WS_OK;
+}
+
+ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_t world_size, int32_t device,
+                                   ws_transport *out)
+{
+    if (!unique_id || !out || world_size == 0 || rank >= world_size) return WS_ERR_INVALID_ARG;
+    if (!load_rccl()) return WS_ERR_COMM;
+    if (hipSetDevice(device) != hipSuccess) return WS_ERR_NO_DEVICE;
+    RcclTransport *t = new RcclTransport();
+    t->rank = (int)rank;
+    t->world = (int)world_size;
+    t->device = device;
+    NcclUniqueId id;
+    memcpy(id.internal, unique_id, sizeof id.internal);
+    if (check(t, g_api.CommInitRank(&t->comm, t->world, id, t->rank), "ncclCommInitRank")) {
+        delete t;
+        return WS_ERR_COMM;
+    }
+    out->ctx = t;
+    out->sendrecv = rccl_sendrecv;
+    out->allgather_dev = rccl_allgather;
+    return WS_OK;
+}
+
+void ws_rccl_transport_destroy(ws_transport *t)
+{
+    if (!t || !t->ctx || t->sendrecv != rccl_sendrecv) return;
+    RcclTransport *r = static_cast<RcclTransport *>(t->ctx);
+    hipSetDevice(r->device);
+    if (r->comm) g_api.CommDestroy(r->comm);
+    delete r;
+    t->ctx = nullptr;
+}
+
+const char *ws_rccl_last_error(void) { return g_api.error.c_str(); }
+
+}  // extern "C"

@@ -155,6 +155,38 @@ class TorchDistTransport(_TransportBase):
             self._fence()
 
 
+class NativeRcclTransport:
+    """The transport inside the library (csrc/ws_rccl.cpp): RCCL send/recv groups and all-gathers issued by the
+    C++ side itself -- no Python in the step.  The host only moves rank 0's 128-byte unique id to every rank."""
+
+    def __init__(self, unique_id, rank, world, device):
+        L = self._L = fluid.load_library()
+        L.ws_rccl_transport_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(WsTransport)]
+        L.ws_rccl_transport_destroy.argtypes = [C.POINTER(WsTransport)]
+        L.ws_rccl_last_error.restype = C.c_char_p
+        assert len(unique_id) == 128
+        self.error = None
+        self.struct = WsTransport()
+        st = L.ws_rccl_transport_create(unique_id, rank, world, device, C.byref(self.struct))
+        if st != 0:
+            raise fluid.WsError(st, "ws_rccl_transport_create: " + (L.ws_rccl_last_error() or b"").decode())
+
+    @staticmethod
+    def unique_id():
+        L = fluid.load_library()
+        L.ws_rccl_unique_id.argtypes = [C.c_char_p]
+        L.ws_rccl_last_error.restype = C.c_char_p
+        buf = C.create_string_buffer(128)
+        st = L.ws_rccl_unique_id(buf)
+        if st != 0:
+            raise fluid.WsError(st, "ws_rccl_unique_id: " + (L.ws_rccl_last_error() or b"").decode())
+        return buf.raw
+
+    def close(self):
+        if self.struct.ctx:
+            self._L.ws_rccl_transport_destroy(C.byref(self.struct))
+
+
 def make_dist_workload(ws, config, dist_name, rank, world, chunk=1 << 22):
     """The N-GPU benchmark workload: the single-GPU config replicated `world` times along x (lattice
     block (ni * world) x nj x nk, container (sx * world) x sy x sz), and this rank's share of it.
