@@ -131,6 +131,28 @@ class FluidWorker {
         check(ws_read_positions(h_, reinterpret_cast<float *>(out.data())));
         return out;
     }
+    // the same into a buffer the host keeps (page-locked once with pin()), optionally overlapped with the next
+    // step: read_positions_begin(buf); run(); read_positions_end();
+    void read_positions_into(std::vector<Vec3> &buf)
+    {
+        buf.resize(n_);
+        check(ws_read_positions(h_, reinterpret_cast<float *>(buf.data())));
+    }
+    void read_positions_begin(std::vector<Vec3> &buf)
+    {
+        if (buf.size() != n_) throw WsError(WS_ERR_INVALID_ARG, "read_positions_begin: wrong buffer size");
+        check(ws_read_positions_begin(h_, reinterpret_cast<float *>(buf.data())));
+    }
+    void read_positions_end() { check(ws_read_positions_end(h_)); }
+    void pin(std::vector<Vec3> &buf) { check(ws_pin_host_buffer(h_, buf.data(), buf.size() * sizeof(Vec3))); }
+    void unpin(std::vector<Vec3> &buf) { check(ws_unpin_host_buffer(h_, buf.data())); }
+    // velocities.length() per particle: the input of update_particle_color, :489-502
+    std::vector<float> read_speeds()
+    {
+        std::vector<float> out(n_);
+        check(ws_read_speeds(h_, out.data()));
+        return out;
+    }
     // the three worker.write calls of update(), :479-481
     void write(const FluidStaticProps &props, const Gravity &gravity, const FluidContainer &container)
     {
