@@ -7,8 +7,10 @@
 //
 // Arithmetic contract: every float expression below is written in the evaluation
 // order of the reference WGSL and this file is compiled with -ffp-contract=off, so
-// each operation is one IEEE binary32 operation (hipcc's default f32 divide and sqrt
-// are correctly rounded).  What differs from the reference is only the ORDER in which
+// each operation is one IEEE binary32 operation, never a contracted multiply-add.  The
+// square root and the divisions of the pair terms come in two forms (template parameter
+// IEEE): correctly rounded, or the hardware's v_sqrt_f32 / v_rcp_f32 (see ws_sqrt /
+// WsDivisor).  What differs from the reference otherwise is only the ORDER in which
 // neighbours are visited (dense-grid order instead of hashed-bucket order).
 #include <stdlib.h>
 
