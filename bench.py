@@ -5,8 +5,18 @@
 
 One "step" = one full pass of the hot path (cell sort -> density -> force -> integrate) over all
 particles, inputs resident in HBM before the timed region, no host readback inside it.  Rank 0
-prints ONE JSON line.  For N > 1 the driver launches this under torch.distributed.run (one rank per
-GPU); see DESIGN.md "Multi-GPU".
+prints ONE JSON line.
+
+The workload is not stationary: a uniform cloud collapses onto the floor within
+~120 steps and the step gets ~3x more expensive, so the line carries TWO windows measured in the same
+run: `value` = steps W..W+K of the trajectory (what the flags ask for), and `settled` = steps
+400..500 (the state the simulation lives in afterwards), each with its own roofline object.
+`value_ieee` is the first window again with WS_FLAG_IEEE_DIVISION (correctly rounded sqrt / division,
+the CPU restatement's arithmetic) instead of the hardware's 1-ULP forms.
+
+For N > 1 the driver launches this under torch.distributed.run (one rank per GPU): N = 4 runs
+BASELINE.json's config 4 (C4, 16 777 216 particles) and N = 8 config 5 (C5, 67 108 864 particles) cut
+into x-slabs; N = 2 runs C3 doubled along x.  See DESIGN.md "Multi-GPU".
 """
 import argparse
 import json
@@ -30,6 +40,15 @@ KERNEL_ALG_BYTES = {
     "force_integrate_bin": B_ALG["K5"] + B_ALG["K6"] + B_ALG["K1"],
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+C3_PARTICLES = 4194304
+SETTLED_FROM = 400     # first step of the settled window
+SETTLED_STEPS = 100
+PROFILES = os.path.join(ROOT, "profiles", "r02")
+
+KERNEL_LABEL = {
+    "density": "density (K4 update_density: radius sweep + accept masks)",
+    "force_integrate_bin": "force_integrate_bin (K5 update_pressure_force + K6 integrate + next K1 binning)",
+}
 
 
 def parse_args():
@@ -37,18 +56,24 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c3", help="c1..c5 | ref (BASELINE.md section 2)")
+    ap.add_argument("--config", default=None, help="c1..c5 | ref (BASELINE.md section 2); default: by --gpus")
     ap.add_argument("--dist", default="cloud", choices=["cloud", "lattice"])
+    ap.add_argument("--replicate", action="store_true",
+                    help="N GPUs: the config replicated N times along x (e.g. --config c3 --replicate: 4 194 304 "
+                         "particles per GPU at every N) instead of BASELINE.json's C4 / C5 geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-settled", action="store_true", help="skip the settled-state window (steps 400..500)")
+    ap.add_argument("--no-ieee", action="store_true", help="skip the WS_FLAG_IEEE_DIVISION repeat of the first window")
     ap.add_argument("--cpu-steps", type=int, default=12,
-                    help="oracle steps timed for cpu_baseline (~10 s of CPU work at C3 on 16 threads)")
+                    help="CPU-restatement steps timed for cpu_baseline (~10 s of CPU work at C3 on 16 threads)")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel table to stderr")
     return ap.parse_args()
 
 
 def cpu_baseline(pos, params, steps):
-    """The CPU restatement of the reference WGSL (oracle, 'fast' sort mode, OpenMP) timed on
-    this host on the SAME workload for a few steps.  Reported, never the target."""
+    """The CPU restatement of the reference WGSL (oracle, 'fast' sort mode: OpenMP over particles, parallel
+    radix sort, parallel cell offsets) timed on this host on the SAME workload for a few steps.  Reported,
+    never the target."""
     from oracle import oracle as O
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,32 +85,73 @@ def cpu_baseline(pos, params, steps):
     for _ in range(steps):
         orc.step(O.SORT_FAST)
     dt = time.perf_counter() - t0
+    try:
+        share = len(os.sched_getaffinity(0))
+    except AttributeError:
+        share = os.cpu_count() or 1
     return {
         "value": steps / dt,
         "unit": "steps/s",
         "cores": O.default_threads(),
         "kind": "port",
-        "sample": "%d full steps of the same %d-particle workload after 1 warm-up step (oracle, fast sort mode)"
-        % (steps, orc.n),
+        "sample": "%d full steps of the same %d-particle workload after 1 warm-up step (CPU restatement of the "
+        "reference WGSL, fast sort mode; %d OpenMP threads of the %d cores this process may run on)"
+        % (steps, orc.n, O.default_threads(), share),
     }
 
 
-KERNEL_LABEL = {
-    "density": "density (K4 update_density: radius sweep + accept masks)",
-    "force_integrate_bin": "force_integrate_bin (K5 update_pressure_force + K6 integrate + next K1 binning)",
-}
-
-
-def load_traffic(config, dist, kernel):
-    """HBM bytes per launch of `kernel` from committed rocprofv3 --pmc passes
-    (profiles/traffic.json), or None if no measurement for this workload is committed."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def load_traffic(config, dist, warmup, steps, kernel):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc pass of EXACTLY this window
+    (profiles/r02/traffic.json, key '<config>-<dist>-w<warmup>-k<steps>'), with its provenance -- or (None, None)
+    when no pass of this window is committed.  Never filled from another window."""
+    path = os.path.join(PROFILES, "traffic.json")
+    key = "%s-%s-w%d-k%d" % (config, dist, warmup, steps)
     try:
         with open(path) as f:
             t = json.load(f)
-        return t.get("%s-%s" % (config, dist), {}).get("bytes_per_launch", {}).get(kernel)
+        v = t.get(key, {}).get("bytes_per_launch", {}).get(kernel)
+        if v is None:
+            return None, None
+        return v, "profiles/r02/traffic.json[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this window" % key
     except (OSError, ValueError):
-        return None
+        return None, None
+
+
+def roofline_of(prof, owned, config, dist, warmup, steps, distributed):
+    """The roofline object of one timed window from the library's HIP-event brackets around the two neighbour kernels."""
+    dominant = max(("density", "force_integrate_bin"), key=lambda k: prof[k][0])
+    ms, cnt = prof[dominant]
+    avg_s = ms / max(cnt, 1) * 1e-3
+    alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
+    achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    traffic, source = (None, None) if distributed else load_traffic(config, dist, warmup, steps, dominant)
+    return {
+        "kernel": KERNEL_LABEL[dominant],
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": source,
+        "alg_bytes_per_launch": alg_bytes,
+        "avg_launch_ms": avg_s * 1e3,
+        "launches_timed": cnt,
+    }
+
+
+def dist_geometry(args, world):
+    """(name, lattice block, container size) of the N-GPU workload.  BASELINE.json: 4 GPUs = config 4 (C4), 8 GPUs =
+    config 5 (C5); it has no 2-GPU config, so N = 2 (and every other N) is C3 replicated N times along x.
+    --config picks another config; --replicate repeats the chosen config N times along x (fixed work per GPU)."""
+    import water_sandbox_amd as ws
+
+    name = args.config or {4: "c4", 8: "c5"}.get(world, "c3")
+    replicate = args.replicate or (args.config is None and world not in (1, 4, 8))
+    block, size = ws.workloads.CONFIGS[name]
+    if replicate and world > 1:
+        return "%sx%d" % (name, world), (block[0] * world, block[1], block[2]), (size[0] * world, size[1], size[2])
+    return name, block, size
 
 
 def main():
@@ -96,7 +162,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
 
     import water_sandbox_amd as ws
@@ -104,7 +170,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # WS_BENCH_FORCE_SLAB=1 runs the slab / torch.distributed path even with one rank (rehearsal on a one-GPU box)
+    # WS_BENCH_FORCE_SLAB=1 runs the slab / RCCL path even with one rank (rehearsal on a one-GPU box)
     distributed = world > 1 or os.environ.get("WS_BENCH_FORCE_SLAB") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -112,10 +178,12 @@ def main():
         local_rank %= torch.cuda.device_count()  # the gloo rehearsal: several ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
 
+    transport = None
     if distributed:
-        # one process per GPU; each owns one x-slab of the (world x wider) domain.  Halos and migrants
-        # move through torch.distributed: backend "nccl" = RCCL over xGMI for device buffers, a gloo
-        # group for the few control words per step (DESIGN.md "Multi-GPU").
+        # one process per GPU; each owns one x-slab of the domain.  Halos and migrants move as RCCL
+        # send/recv with the two x-neighbours, issued by the library itself (csrc/ws_rccl.cpp): no Python in the
+        # step.  torch.distributed only bootstraps (rank 0's RCCL unique id -> every rank) and provides the
+        # barrier / max-over-ranks of the timing contract.
         import torch.distributed as dist
 
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
@@ -128,74 +196,113 @@ def main():
         else:
             dist.init_process_group(backend)
         ctrl = dist.new_group(backend="gloo")
-        # the library enqueues on the stream RCCL's point-to-point calls are ordered on: an explicit,
-        # non-default torch stream made current for the whole run (the default stream's handle is 0,
-        # which ws_device_cfg.stream reads as "create your own")
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
-        pos, ids, n_global, params = ws.slab.make_dist_workload(ws, args.config, args.dist, rank, world)
-        if os.environ.get("WS_TRANSPORT", "torch") == "rccl":
-            # the library's own RCCL transport: torch.distributed only carries rank 0's unique id to the others
+        cfg_name, block, size = dist_geometry(args, world)
+        base_name = cfg_name.split("x")[0]
+        pos, ids, n_global, params = ws.slab.make_dist_workload(ws, block, size, args.dist, rank, world,
+                                                                seed=ws.workloads.cloud_seed(base_name))
+        which = os.environ.get("WS_TRANSPORT", "rccl" if backend == "nccl" else "torch")
+        if which == "rccl":
             box = [ws.slab.NativeRcclTransport.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=ctrl)
             transport = ws.slab.NativeRcclTransport(box[0], rank, world, local_rank)
         else:
             transport = ws.slab.TorchDistTransport(rank, world, local_rank, data_group=None, ctrl_group=ctrl)
-        worker = ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
-                                    stream=torch.cuda.current_stream().cuda_stream, profile=True)
-        n_rank = n_global // world  # particles per rank at t = 0 (the single-GPU config's count)
+
+        def make_worker(ieee=False):
+            return ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
+                                      stream=None if which == "rccl" else torch.cuda.current_stream().cuda_stream,
+                                      profile=True, ieee_division=ieee)
     else:
-        pos, params = ws.workloads.make_workload(args.config, args.dist)
-        n_global = n_rank = pos.shape[0]
-        worker = ws.FluidWorker(pos, params, device=local_rank, profile=True)
-    # HIP events bracket only the two neighbour kernels inside the timed region (4 records per step, on the
+        cfg_name = base_name = args.config or "c3"
+        pos, params = ws.workloads.make_workload(cfg_name, args.dist)
+        n_global = pos.shape[0]
+
+        def make_worker(ieee=False):
+            return ws.FluidWorker(pos, params, device=local_rank, profile=True, ieee_division=ieee)
+
+    # HIP events bracket only the two neighbour kernels inside the timed regions (4 records per step, on the
     # library's stream): one of them is the dominant kernel, and bracketing all five launches costs several
     # per cent of a sub-millisecond step
-    worker.profile_select((1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"]))
+    neighbour_mask = (1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"])
 
-    def barrier():
+    def barrier(worker):
         worker.sync()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
 
+    def timed_window(worker, steps):
+        """Time exactly `steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
+        barrier(worker)
+        worker.profile_reset()
+        t0 = time.perf_counter()
+        worker.run(steps)
+        barrier(worker)
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, worker.profile()
+
+    worker = make_worker()
+    worker.profile_select(neighbour_mask)
     worker.run(args.warmup)
-    barrier()
-    worker.profile_reset()
-    t0 = time.perf_counter()
-    worker.run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    prof = worker.profile()
-    dominant = max(("density", "force_integrate_bin"), key=lambda k: prof[k][0])
-    force_ms, force_cnt = prof[dominant]
+    elapsed, prof = timed_window(worker, args.steps)
+    owned = worker.num_owned() if distributed else n_global
     breakdown = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]}
-    owned = worker.num_owned() if distributed else n_rank
+    roof = roofline_of(prof, owned, cfg_name, args.dist, args.warmup, args.steps, distributed)
+
+    settled = None
+    done = args.warmup + args.steps
+    if not args.no_settled and done <= SETTLED_FROM:
+        worker.run(SETTLED_FROM - done)
+        s_elapsed, s_prof = timed_window(worker, SETTLED_STEPS)
+        s_owned = worker.num_owned() if distributed else n_global
+        settled = {
+            "window": "steps %d..%d of the same trajectory" % (SETTLED_FROM, SETTLED_FROM + SETTLED_STEPS),
+            "warmup": SETTLED_FROM,
+            "steps": SETTLED_STEPS,
+            "ms_per_step": s_elapsed / SETTLED_STEPS * 1e3,
+            "global_steps_per_s": SETTLED_STEPS / s_elapsed,
+            "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in s_prof.items() if v[1]},
+            "roofline": roofline_of(s_prof, s_owned, cfg_name, args.dist, SETTLED_FROM, SETTLED_STEPS, distributed),
+        }
     if args.breakdown and not distributed and rank == 0:
-        # per-kernel table from a separate short pass AFTER the timed region (later steps of the trajectory)
         worker.profile_select(0xFFFFFFFF)
         worker.profile_reset()
-        worker.run(min(args.steps, 20))
+        worker.run(20)
         worker.sync()
-        breakdown = {k: (v[0] / max(v[1], 1)) for k, v in worker.profile().items() if v[1]}
+        for k, v in sorted(worker.profile().items(), key=lambda kv: -kv[1][0]):
+            if v[1]:
+                print("%-22s %9.3f ms" % (k, v[0] / v[1]), file=sys.stderr)
+    stats = worker.stats() if not distributed else None
+    grid = list(worker.grid_dims()) if not distributed else None
+    worker.close()
+
+    ieee = None
+    if not args.no_ieee and not distributed:
+        w2 = make_worker(ieee=True)
+        w2.profile_select(neighbour_mask)
+        w2.run(args.warmup)
+        i_elapsed, i_prof = timed_window(w2, args.steps)
+        ieee = {"ms_per_step": i_elapsed / args.steps * 1e3, "global_steps_per_s": args.steps / i_elapsed,
+                "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in i_prof.items() if v[1]}}
+        w2.close()
 
     if rank == 0:
         global_steps_per_s = args.steps / elapsed
-        # unit of work = one step of one rank's 4 194 304-particle (config-sized) share; all ranks
-        # together process `world` of them per global step (weak scaling), so the whole-job value is
-        # world x global steps/s.  At world = 1 this is plain simulation steps/s.
-        value = world * global_steps_per_s
-        force_avg_s = force_ms / max(force_cnt, 1) * 1e-3
-        alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
-        achieved = alg_bytes / force_avg_s / 1e9
-        dist_name = ("uniform cloud seed 0x%X" % ws.workloads.cloud_seed(args.config)) if args.dist == "cloud" \
+        # Unit of work = one step of a C3-sized (4 194 304-particle) share: the whole-job value is the global
+        # step rate times the number of such shares the job's configuration holds (1 at C3, 4 at C4, 16 at C5),
+        # so that value(N) / (N x value(1)) is the scaling efficiency.  The absolute step rate at the
+        # configuration's own size -- BASELINE.json's "steps/sec @ N particles" -- is global_steps_per_s.
+        shares = n_global / C3_PARTICLES if distributed else 1.0
+        dist_name = ("uniform cloud seed 0x%X" % ws.workloads.cloud_seed(base_name)) if args.dist == "cloud" \
             else "cube_fluid lattice"
         out = {
             "metric": "simulation steps/sec @ N particles",
-            "value": value,
+            "value": shares * global_steps_per_s,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -207,47 +314,46 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s%s: %d particles, 3D, %s, reference default parameters; steps %d..%d of the trajectory"
-                % (args.config.upper(), (" x%d along x (one x-slab per GPU)" % world) if distributed else "", n_global,
-                   dist_name, args.warmup, args.warmup + args.steps),
+                "workload": "%s: %d particles, 3D, %s, reference default parameters%s; steps %d..%d of the trajectory"
+                % (cfg_name.upper(), n_global, dist_name, (", %d x-slabs (one per GPU)" % world) if distributed else "",
+                   args.warmup, args.warmup + args.steps),
                 "particles": n_global,
-                "particles_per_gpu": n_rank,
+                "particles_per_gpu": n_global // world,
                 "distribution": args.dist,
                 "container": [params.ext_min[i] for i in range(3)] + [params.ext_max[i] for i in range(3)],
-                "value_definition": "n_gpus x global simulation steps/s (each GPU steps a %d-particle share)" % n_rank,
+                "value_definition": "global simulation steps/s x (particles / 4 194 304): steps of a C3-sized share per "
+                                    "second, whole job; global_steps_per_s is the absolute step rate at this particle count",
+                "arithmetic": "f32, every operation rounded as written (no FMA contraction); sqrt / division of the pair "
+                              "terms: hardware v_sqrt_f32 / v_rcp_f32 (1 ULP) -- value_ieee: correctly rounded",
                 "readback_in_timed_region": False,
             },
             "global_steps_per_s": global_steps_per_s,
             "particle_steps_per_s": global_steps_per_s * n_global,
             "algorithmic_GBps_step": B_ALG_STEP * n_global * global_steps_per_s / 1e9,
-            "roofline": {
-                "kernel": KERNEL_LABEL[dominant],
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(args.config, args.dist, dominant) if not distributed else None,
-                "alg_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": force_avg_s * 1e3,
-                "launches_timed": force_cnt,
-            },
+            "roofline": roof,
             "kernel_ms": breakdown,
+            "settled": settled,
         }
-        if not distributed:
-            out["config"]["grid_cells"] = list(worker.grid_dims())
-            out["stats"] = worker.stats()
+        if settled is not None:
+            settled["value"] = shares * settled["global_steps_per_s"]
+            settled["algorithmic_GBps_step"] = B_ALG_STEP * n_global * settled["global_steps_per_s"] / 1e9
+        if ieee is not None:
+            out["value_ieee"] = shares * ieee["global_steps_per_s"]
+            out["ieee"] = ieee
+        if transport is not None:
+            out["config"]["transport"] = type(transport).__name__
+        if grid is not None:
+            out["config"]["grid_cells"] = grid
+            out["stats"] = stats
         if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(pos, params, args.cpu_steps)
         else:
             out["cpu_baseline"] = None
-        if args.breakdown:
-            for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]):
-                print("%-22s %9.3f ms" % (k, v), file=sys.stderr)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    worker.close()
     if distributed:
         dist.barrier()
+        if hasattr(transport, "close"):
+            transport.close()
         dist.destroy_process_group()
 
 

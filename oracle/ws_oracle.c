@@ -254,24 +254,63 @@ void wso_sort_exact(wso_state *s)
             wso_bitonic_sort_stage(s, (uint32_t)block, (uint32_t)dim);
 }
 
-/* Timing mode: a stable counting sort of the persisted permutation by key.  Gives
- * the same sorted key sequence and cell offsets as the network; the order inside a
- * bucket (hence float summation order) differs. */
+/* Timing mode ("OpenMP over particles and a parallel sort"): a stable LSD radix sort of
+ * the persisted permutation by key, 11 bits per pass, each pass a parallel counting sort (per-thread
+ * histograms over contiguous chunks, so equal keys keep their order).  Gives the same sorted key
+ * sequence and cell offsets as the network; the order inside a bucket (hence float summation order)
+ * differs -- it is the order a stable sort of the previous permutation gives. */
+#define WSO_RADIX_BITS 11
+#define WSO_RADIX (1u << WSO_RADIX_BITS)
 void wso_sort_fast(wso_state *s)
 {
     const uint32_t n = s->num_particles;
-    uint32_t *count = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
-    uint32_t *tmp = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    if (n < 2) return;
     const uint32_t *key = s->particle_cell_indicies;
-    for (uint32_t i = 0; i < n; i++) count[key[s->particle_indicies[i]] + 1]++;
-    for (uint32_t k = 0; k < n; k++) count[k + 1] += count[k];
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t pid = s->particle_indicies[i];
-        tmp[count[key[pid]]++] = pid;
+    uint32_t *a = s->particle_indicies;
+    uint32_t *b = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    int bits = 0;
+    while (((uint64_t)1 << bits) < n) bits++; /* keys are < n */
+    const int nthreads = wso_max_threads();
+    uint32_t *hist = (uint32_t *)malloc((size_t)nthreads * WSO_RADIX * sizeof(uint32_t));
+    for (int shift = 0; shift < bits; shift += WSO_RADIX_BITS) {
+#pragma omp parallel num_threads(nthreads)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+            const int t = 0, T = 1;
+#endif
+            uint32_t *h = hist + (size_t)t * WSO_RADIX;
+            memset(h, 0, WSO_RADIX * sizeof(uint32_t));
+            const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+            for (uint32_t i = lo; i < hi; i++) h[(key[a[i]] >> shift) & (WSO_RADIX - 1u)]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                uint32_t run = 0; /* digit-major, thread-minor: stable */
+                for (uint32_t d = 0; d < WSO_RADIX; d++)
+                    for (int q = 0; q < T; q++) {
+                        uint32_t *c = hist + (size_t)q * WSO_RADIX + d;
+                        const uint32_t v = *c;
+                        *c = run;
+                        run += v;
+                    }
+            }
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint32_t pid = a[i];
+                b[h[(key[pid] >> shift) & (WSO_RADIX - 1u)]++] = pid;
+            }
+        }
+        uint32_t *sw = a;
+        a = b;
+        b = sw;
     }
-    memcpy(s->particle_indicies, tmp, (size_t)n * sizeof(uint32_t));
-    free(tmp);
-    free(count);
+    if (a != s->particle_indicies) {
+        memcpy(s->particle_indicies, a, (size_t)n * sizeof(uint32_t));
+        b = a;
+    }
+    free(b);
+    free(hist);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -280,9 +319,23 @@ void wso_sort_fast(wso_state *s)
 void wso_calculate_cell_offsets(wso_state *s)
 {
     const uint32_t n = s->num_particles;
+    const uint32_t *idx = s->particle_indicies, *key = s->particle_cell_indicies;
+    /* atomicMin(cell_offsets[key], index) over a sorted sequence = the first slot of each key:
+     * when the keys are in ascending slot order (always, after either sort) every head slot can be
+     * written independently; otherwise fall back to the literal serial minimum. */
+    int sorted = 1;
+#pragma omp parallel for schedule(static) reduction(&& : sorted)
+    for (uint32_t index = 1; index < n; index++) sorted = sorted && key[idx[index - 1]] <= key[idx[index]];
+    if (sorted) {
+#pragma omp parallel for schedule(static)
+        for (uint32_t index = 0; index < n; index++) {
+            const uint32_t cell_index = key[idx[index]];
+            if (index == 0 || key[idx[index - 1]] != cell_index) s->cell_offsets[cell_index] = index;
+        }
+        return;
+    }
     for (uint32_t index = 0; index < n; index++) {
-        const uint32_t pid = s->particle_indicies[index];
-        const uint32_t cell_index = s->particle_cell_indicies[pid];
+        const uint32_t cell_index = key[idx[index]];
         if (index < s->cell_offsets[cell_index]) s->cell_offsets[cell_index] = index; /* atomicMin */
     }
 }

@@ -26,3 +26,10 @@ def ws():
 
     ws.load_library()
     return ws
+
+
+@pytest.fixture(scope="session")
+def refcheck(ws):
+    """The TEST-ONLY build of the library that also contains the reference-order validation kernels
+    (tests/libwsfluid_refcheck.so; the product library refuses WS_FLAG_REFERENCE_ORDER)."""
+    return ws.fluid.bind_library(ws.build.build_refcheck_library())

@@ -102,3 +102,53 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("oracle's", "").lower() or f == "README", (dirpath, f)
+
+
+def test_product_library_does_not_contain_the_reference_order_port(ws):
+    """The literal HIP restatement of the reference's WGSL passes (kr_* kernels) is test infrastructure: it is
+    compiled into tests/libwsfluid_refcheck.so only, and the shipped library refuses WS_FLAG_REFERENCE_ORDER."""
+    product = open(ws.build.build_library(), "rb").read()
+    check = open(ws.build.build_refcheck_library(), "rb").read()
+    for name in (b"kr_bitonic", b"kr_density", b"kr_force", b"kr_integrate"):
+        assert name not in product, name
+        assert name in check, name
+    assert b"k_force_listed" in product and b"k_density_listed" in product
+    cfg = ws.fluid.WsDeviceCfg()
+    cfg.flags = ws.fluid.WS_FLAG_REFERENCE_ORDER
+    h = C.c_void_p()
+    p = ws.default_params()
+    pos = np.zeros((4, 3), np.float32)
+    assert ws.load_library().ws_create(C.byref(p), pos.ctypes.data, 4, C.byref(cfg), C.byref(h)) == 6  # WS_ERR_UNSUPPORTED
+    assert not h
+
+
+def test_header_is_plain_c_and_binds_without_hip(ws, tmp_path):
+    """include/wsfluid.h must be consumable by a C compiler (bindgen / cgo / a C host): compile a C11 translation
+    unit against it with gcc -pedantic, link it to libwsfluid.so and run the host-only entry points."""
+    import subprocess
+
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "wsfluid.h"
+int main(void) {
+    ws_params p; ws_smoothing_kernel k; float lattice[3 * 8]; float mn[4], mx[4];
+    const float position[3] = {0.f, 0.f, 0.f}, size[3] = {16.f, 9.f, 9.f};
+    if (sizeof(ws_particle80) != 80 || sizeof(ws_params) != 80) return 2;
+    if (ws_abi_version() != WS_ABI_VERSION) return 3;
+    if (ws_default_params(&p) != WS_OK || ws_get_smoothing_kernel(&p, &k) != WS_OK) return 4;
+    if (ws_cube_fluid(2, 2, 2, 0.1f, lattice) != WS_OK || ws_get_ext(position, size, 0.1f, mn, mx) != WS_OK) return 5;
+    if (ws_bit_sorter_stage_count(4096) != 78) return 6;
+    if (ws_step(NULL) != WS_ERR_INVALID_ARG) return 7;
+    printf("%.6f %.3f %.1f %s\n", (double)p.delta_time, (double)k.pow2, (double)mx[0], ws_status_string(WS_ERR_NO_DEVICE));
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(ws.build.build_library())
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lwsfluid", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.split()[:3] == ["0.016667", "2444.620", "7.9"]

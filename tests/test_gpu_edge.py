@@ -38,10 +38,13 @@ def test_tiny_n_hash_aliasing(oracle, ws, n):
         assert got["density"][0, 0] == pytest.approx(27 * 0.0625 * k.pow2 + 1e-5, rel=1e-6)
 
 
-@pytest.mark.parametrize("n", [1000, 3000])
+@pytest.mark.parametrize("n", [1000, 3000, 15823, 31646])
 def test_non_power_of_two_n(oracle, ws, n):
     """The reference's bitonic sort needs a power of two (src/fluid_compute.rs:15 FIXME); the counting
-    sort here does not.  Oracle in fast-sort mode defines the expected values."""
+    sort here does not.  Oracle in fast-sort mode defines the expected values.  15 823 is the x prime of
+    hash_cell (and 31 646 twice it): there the x-neighbour cells of every cell share one bucket of the
+    reference's table and the reference counts such neighbours three times; the HIP path reproduces it
+    (per-pair multiplicity for a non-power-of-two N whose stencil can alias)."""
     mn, mx = ws.get_ext((0, 0, 0), (6.0, 4.0, 4.0), 0.1)
     pos = ws.workloads.uniform_cloud(n, 99, mn, mx)
     _one_step_parity(oracle, ws, pos, ws.make_params(container_size=(6.0, 4.0, 4.0)), mode=oracle.SORT_FAST,
@@ -122,15 +125,26 @@ def test_reset_restores_initial_state_and_identity_views(ws):
 
 
 def test_step_is_asynchronous_and_ready_polls(ws):
-    pos, params = ws.workloads.make_workload("c2", "cloud")
+    """`ws_step` only enqueues (AppComputeWorker::run) and `ws_ready` polls without blocking (::ready,
+    src/fluid_compute.rs:474): with 40 C3 steps queued (>= 20 ms of GPU work, enqueued in ~2 ms) the handle must
+    report busy, the enqueue must return long before the work is done, and after ws_sync it must report ready."""
+    import time
+
+    pos, params = ws.workloads.make_workload("c3", "cloud")
     w = ws.FluidWorker(pos, params)
-    assert w.ready()
-    w.run(50)
-    seen_busy = not w.ready()
+    w.run(2)
     w.sync()
     assert w.ready()
-    assert w.steps_done() == 50
-    assert seen_busy or True  # on a fast GPU the queue may already be drained; the poll must not block
+    t0 = time.perf_counter()
+    w.run(40)
+    t_enqueued = time.perf_counter() - t0
+    busy = not w.ready()
+    w.sync()
+    t_done = time.perf_counter() - t0
+    assert busy, "ws_ready reported 1 with 40 steps of 4 194 304 particles still queued"
+    assert t_enqueued < 0.5 * t_done, "ws_step blocked: enqueue %.1f ms of %.1f ms" % (t_enqueued * 1e3, t_done * 1e3)
+    assert w.ready()
+    assert w.steps_done() == 42
     w.close()
 
 

@@ -1,4 +1,5 @@
-"""Reference-order mode (WS_FLAG_REFERENCE_ORDER): the reference's passes executed literally on the GPU.
+"""Reference-order mode (WS_FLAG_REFERENCE_ORDER): the reference's passes executed literally on the GPU, by the
+TEST-ONLY build of the library (tests/libwsfluid_refcheck.so; the shipped libwsfluid.so does not contain them).
 Against the oracle's exact mode EVERYTHING must be bit-identical, free-running: the permutation the
 bitonic network leaves behind, hash keys, cell offsets and every float of the 80-byte records."""
 import numpy as np
@@ -23,10 +24,10 @@ def _compare(w, orc, label):
 
 
 @pytest.mark.parametrize("name,dist", [("c1", "lattice"), ("c1", "cloud")])
-def test_free_running_bit_identical_to_oracle(oracle, ws, name, dist):
+def test_free_running_bit_identical_to_oracle(oracle, ws, refcheck, name, dist):
     pos, params = ws.workloads.make_workload(name, dist)
     orc = oracle_from_params(oracle, pos, params)
-    w = ws.FluidWorker(pos, params, reference_order=True)
+    w = ws.FluidWorker(pos, params, reference_order=True, library=refcheck)
     _compare(w, orc, "t=0")  # identity index buffers, zero fields
     for s in range(1, 13):
         orc.step(oracle.SORT_EXACT)
@@ -35,11 +36,11 @@ def test_free_running_bit_identical_to_oracle(oracle, ws, name, dist):
     w.close()
 
 
-def test_cube_4096_with_param_change_and_reset(oracle, ws):
+def test_cube_4096_with_param_change_and_reset(oracle, ws, refcheck):
     pos = ws.cube_fluid(16, 16, 16)
     params = ws.default_params()
     orc = oracle_from_params(oracle, pos, params)
-    w = ws.FluidWorker(pos, params, reference_order=True)
+    w = ws.FluidWorker(pos, params, reference_order=True, library=refcheck)
     for s in range(5):
         orc.step(oracle.SORT_EXACT); w.run()
     _compare(w, orc, "before change")
@@ -62,11 +63,11 @@ def test_cube_4096_with_param_change_and_reset(oracle, ws):
 
 
 @pytest.mark.parametrize("name", G.CASES)
-def test_reference_order_reproduces_golden_bitwise(ws, name):
+def test_reference_order_reproduces_golden_bitwise(ws, refcheck, name):
     g = G.load(name)
     pos = G.initial_positions(ws.workloads if int(g["gen_is_cloud"]) else ws, g)
     w = ws.FluidWorker(pos, ws.make_params(container_size=tuple(float(x) for x in g["container_size"])),
-                       reference_order=True)
+                       reference_order=True, library=refcheck)
     for s in range(1, 11):
         w.run()
         if s == 1:
@@ -84,13 +85,13 @@ def test_reference_order_reproduces_golden_bitwise(ws, name):
     w.close()
 
 
-def test_fast_path_agrees_with_reference_order_within_reorder_noise(oracle, ws):
+def test_fast_path_agrees_with_reference_order_within_reorder_noise(oracle, ws, refcheck):
     """The production kernels against the literal GPU execution of the reference, one step from the same
     state: same integer artefacts, floats within the reorder-noise tolerance."""
     from util import assert_particles_close, oracle_one_step, reorder_noise_tolerances
 
     pos, params = ws.workloads.make_workload("ref", "lattice")  # the reference's own 65 536-particle default
-    ref = ws.FluidWorker(pos, params, reference_order=True)
+    ref = ws.FluidWorker(pos, params, reference_order=True, library=refcheck)
     fast = ws.FluidWorker(pos, params)
     ref.run(5)
     state = ref.read_vec("particles")
@@ -104,3 +105,11 @@ def test_fast_path_agrees_with_reference_order_within_reorder_noise(oracle, ws):
     ka, pa, oa = ref.sort_view(); kb, pb, ob = fast.sort_view()
     assert np.array_equal(ka, kb) and np.array_equal(ka[pa], kb[pb]) and np.array_equal(oa, ob)
     ref.close(); fast.close()
+
+
+def test_the_product_library_refuses_reference_order(ws):
+    """libwsfluid.so ships only the MI355X-native path: the validation mode is compiled into the test-only
+    library alone, and asking the product for it fails loudly (WS_ERR_UNSUPPORTED), never silently falls back."""
+    with pytest.raises(ws.WsError) as e:
+        ws.FluidWorker(ws.cube_fluid(4, 4, 4), ws.default_params(), reference_order=True)
+    assert e.value.status == 6  # WS_ERR_UNSUPPORTED

@@ -45,7 +45,7 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     env = dict(os.environ, WS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--config", "c1"]
+           "--config", "c1", "--replicate"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -53,5 +53,7 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["unit"] == "steps/s" and line["value"] > 0 and line["config"]["particles"] == 2 * 4096
-    assert abs(line["value"] - 2 * line["global_steps_per_s"]) < 1e-9 * line["value"]
+    shares = line["config"]["particles"] / 4194304.0  # value counts steps of C3-sized shares
+    assert abs(line["value"] - shares * line["global_steps_per_s"]) < 1e-9 * line["value"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert line["settled"] is not None and line["settled"]["steps"] == 100 and line["settled"]["warmup"] == 400

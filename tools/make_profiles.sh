@@ -1,21 +1,26 @@
 #!/bin/bash
-# Regenerate the round's judged artefacts on the GPU box (run through gpurun from the repo root):
-#   bench lines (cloud + lattice), rocprofv3 --kernel-trace --stats of the SAME bench command,
-#   FETCH_SIZE / WRITE_SIZE passes, variant A/B table.  Outputs land in gpurun_out/r01/.
+# Regenerate the round's judged artefacts on the GPU box (run through gpurun from the repo root).
+# Everything lands in gpurun_out/r02/; copy what is judged into profiles/r02/ afterwards (tools/collect_profiles.sh).
+#   1. the bench line of EXACTLY the driver's command (python3 bench.py --gpus 1 --steps 20 --warmup 5)
+#   2. rocprofv3 --kernel-trace --stats of the same command (+ per-window summary cut from its trace)
+#   3. FETCH_SIZE / WRITE_SIZE in separate --pmc passes for the driver window and the settled window
+#   4. the default bench line (10..110) and the lattice / C2 lines
 set -e
 export TMPDIR=/tmp
-out=gpurun_out/r01; mkdir -p $out
-python bench.py > $out/bench_c3_cloud.json 2> $out/bench_c3_cloud.err
-python bench.py --dist lattice --no-cpu-baseline > $out/bench_c3_lattice.json 2> $out/bench_c3_lattice.err
-python bench.py --config c2 --no-cpu-baseline > $out/bench_c2_cloud.json 2> $out/bench_c2_cloud.err
-rm -rf $GRAFT_REPO_ROOT/$out/rocprof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rocprof_bench -- python3 bench.py --no-cpu-baseline > $out/rocprof_bench.json 2> $out/rocprof_bench.err
-tools/traffic.sh c3 cloud 10 100
-: > $out/variants.log
-for w in 10 60 200; do
-  WS_VARIANT=simple python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
-  WS_VARIANT=simple WS_IEEE=1 python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
-  python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
-  WS_IEEE=1 python tools/probe.py c3 cloud $w 20 2>/dev/null | grep '^{' >> $out/variants.log
-done
+out=gpurun_out/r02; mkdir -p $out
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err
+echo "bench driver cmd done"
+rm -rf $GRAFT_REPO_ROOT/$out/rocprof_driver_cmd
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rocprof_driver_cmd -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/rocprof_driver_cmd.json 2> $out/rocprof_driver_cmd.err
+trace=$(ls $out/rocprof_driver_cmd/*/*_kernel_trace.csv | head -1)
+stats=$(ls $out/rocprof_driver_cmd/*/*_kernel_stats.csv | head -1)
+python3 tools/window_stats.py $trace 5 20 > $out/rocprof_driver_cmd_windows.json
+cp $stats $out/rocprof_driver_cmd_kernel_stats.csv
+echo "rocprof done"
+tools/traffic.sh c3 cloud 5 20 && python3 tools/traffic_report.py c3 cloud 5 20 4194304 $out/traffic.json
+tools/traffic.sh c3 cloud 400 100 && python3 tools/traffic_report.py c3 cloud 400 100 4194304 $out/traffic.json
+echo "traffic done"
+python3 bench.py > $out/bench_c3_cloud.json 2> $out/bench_c3_cloud.err
+python3 bench.py --dist lattice --no-cpu-baseline > $out/bench_c3_lattice.json 2> $out/bench_c3_lattice.err
+python3 bench.py --config c2 --no-cpu-baseline > $out/bench_c2_cloud.json 2> $out/bench_c2_cloud.err
 echo done

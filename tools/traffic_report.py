@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Fold tools/traffic.sh output into profiles/traffic.json.
+"""Fold tools/traffic.sh output into profiles/r02/traffic.json (one entry per window).
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports exactly half the bytes of a wide
 coalesced streaming read (MI355X_MICROARCH.md, HBM): the raw value, the x2-corrected value and the
 calibration against k_reorder (a pure streaming kernel of known byte count in this library) are
 all recorded; bench.py reports the corrected figure."""
 import collections, csv, glob, json, os, sys
 cfg, dist, warm, steps, n = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+out_path = sys.argv[6] if len(sys.argv) > 6 else None  # default: profiles/r02/traffic.json
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def per_kernel(kind, counter):
     f = max(glob.glob(os.path.join(root, "gpurun_out", "traffic_%s_%s_%s" % (cfg, dist, kind), "*", "*_counter_collection.csv")),
@@ -29,8 +30,8 @@ dens = [k for k in fetch if k.startswith("k_density")][0]
 out["bytes_per_launch"] = {"force_integrate_bin": 2.0 * fetch[force] + write[force],
                            "density": 2.0 * fetch[dens] + write[dens]}
 out["bytes_per_launch_note"] = "2 x FETCH_SIZE (gfx950 half-count correction for 16-B/lane reads) + WRITE_SIZE"
-path = os.path.join(root, "profiles", "traffic.json")
+path = out_path or os.path.join(root, "profiles", "r02", "traffic.json")
 allt = json.load(open(path)) if os.path.exists(path) else {}
-allt["%s-%s" % (cfg, dist)] = out
+allt["%s-%s-w%d-k%d" % (cfg, dist, warm, steps)] = out  # keyed by window: bench.py fills roofline.traffic on an exact match only
 json.dump(allt, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: out[k] for k in ("bytes_per_launch", "calibration")}, indent=1))

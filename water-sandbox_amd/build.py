@@ -9,6 +9,11 @@ LIB = os.path.join(HERE, "libwsfluid.so")
 
 SOURCES = ["ws_kernels.hip", "ws_api.cpp", "ws_rccl.cpp"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
+# Test-only build of the same sources plus the reference-order validation kernels (ws_refcheck.inc, a literal
+# HIP restatement of the reference's six WGSL passes used by the tests as a second, independent restatement).  It lives under
+# tests/, is built by __graft_entry__.build() and is never loaded by the product package.
+REFCHECK_LIB = os.path.join(ROOT, "tests", "libwsfluid_refcheck.so")
+REFCHECK_EXTRA = [os.path.join(CSRC, "ws_refcheck.inc")]
 
 # -ffp-contract=off: every float op in the kernels is one IEEE binary32 op, written in the
 # reference WGSL's evaluation order (no FMA contraction), see ws_kernels.hip.
@@ -25,26 +30,42 @@ def hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _stale(lib, extra=()):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + list(extra)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB)
+
+
+def _compile(lib, defines, verbose):
+    cmd = [hipcc()] + HIPCC_FLAGS + defines + [
+        "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", lib,
+    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return lib
 
 
 def build_library(force=False, verbose=False):
     """Compile the shared library if it is missing or older than its sources."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + HIPCC_FLAGS + [
-        "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB,
-    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return _compile(LIB, [], verbose)
+
+
+def build_refcheck_library(force=False, verbose=False):
+    """Compile the TEST-ONLY library (product sources + the reference-order validation kernels)."""
+    if not force and not _stale(REFCHECK_LIB, REFCHECK_EXTRA):
+        return REFCHECK_LIB
+    return _compile(REFCHECK_LIB, ["-DWS_WITH_REFCHECK"], verbose)
 
 
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_refcheck_library(force=True, verbose=True))

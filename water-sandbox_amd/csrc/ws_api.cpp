@@ -73,10 +73,13 @@ float accept_threshold(float h)
 
 bool is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
 
-uint32_t ref_hash_delta(int x, int y, int z, uint32_t n)
+// hash_cell before its `% N`, assets/simulation.wgsl:125-128 (u32 wrap arithmetic)
+uint32_t ref_linear(int x, int y, int z)
 {
-    return ((uint32_t)x * 15823u + (uint32_t)y * 9737333u + (uint32_t)z * 440817757u) % n;
+    return (uint32_t)x * 15823u + (uint32_t)y * 9737333u + (uint32_t)z * 440817757u;
 }
+
+uint32_t ref_hash_delta(int x, int y, int z, uint32_t n) { return ref_linear(x, y, z) % n; }
 
 ws_status validate_params(ws_handle *h, const ws_params *p)
 {
@@ -178,6 +181,13 @@ ws_status alloc_grid(ws_handle *h)
     return WS_OK;
 }
 
+// Does the reference's N-bucket table put two cells of one 27-stencil into the same bucket?  Then a neighbour
+// is visited once per aliasing stencil cell (the reference counts it that often) and the kernels take the
+// multiplicity path (`alias`).  Power-of-two N: hash_cell is linear mod N, the multiplicity depends on the
+// cell difference only and is tabulated here.  Any other N: `% N` follows a wrap mod 2^32, so two stencil cells
+// whose linear forms differ by delta can alias iff delta, delta - 2^32 or delta + 2^32 is a multiple of N (which
+// of them applies depends on the cell); if none of the 27 x 26 differences qualifies no particle can ever see an
+// aliased bucket, otherwise the kernels count the aliasing offsets per pair (alias_mult).
 ws_status upload_mult(ws_handle *h)
 {
     uint8_t m[27];
@@ -186,19 +196,24 @@ ws_status upload_mult(ws_handle *h)
     for (int dx = -1; dx <= 1; dx++)
         for (int dy = -1; dy <= 1; dy++)
             for (int dz = -1; dz <= 1; dz++) {
-                uint32_t cnt = 1;
-                if (is_pow2(n)) {
-                    // hash_cell is linear mod N for power-of-two N (the only N the reference's
-                    // sort supports, src/fluid_compute.rs:15): offsets o with hash(o) == hash(delta)
-                    cnt = 0;
-                    const uint32_t hd = ref_hash_delta(dx, dy, dz, n);
-                    for (int ox = -1; ox <= 1; ox++)
-                        for (int oy = -1; oy <= 1; oy++)
-                            for (int oz = -1; oz <= 1; oz++)
-                                if (ref_hash_delta(ox, oy, oz, n) == hd) cnt++;
-                }
+                uint32_t cnt = 0;
+                for (int ox = -1; ox <= 1; ox++)
+                    for (int oy = -1; oy <= 1; oy++)
+                        for (int oz = -1; oz <= 1; oz++) {
+                            if (is_pow2(n)) {
+                                if (ref_hash_delta(ox, oy, oz, n) == ref_hash_delta(dx, dy, dz, n)) cnt++;
+                                continue;
+                            }
+                            if (ox == dx && oy == dy && oz == dz) {
+                                cnt++;
+                                continue;
+                            }
+                            const int64_t delta = (int64_t)ref_linear(ox, oy, oz) - (int64_t)ref_linear(dx, dy, dz);
+                            for (int64_t k = -1; k <= 1; k++)
+                                if ((delta + k * ((int64_t)1 << 32)) % (int64_t)n == 0) alias = true;
+                        }
                 if (cnt > 1) alias = true;
-                m[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = (uint8_t)cnt;
+                m[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = (uint8_t)(cnt ? cnt : 1);
             }
     h->alias = alias;
     if (!h->mult) HIP_TRY(h, hipMalloc(&h->mult, 32));
@@ -495,6 +510,11 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     ws_status st = validate_params(nullptr, params);
     if (st) return st;
     if (cfg && cfg->world_size > 1) return fail(nullptr, WS_ERR_UNSUPPORTED, "multi-GPU slabs are created with ws_create_slab");
+#ifndef WS_WITH_REFCHECK
+    if (cfg && (cfg->flags & WS_FLAG_REFERENCE_ORDER))
+        return fail(nullptr, WS_ERR_UNSUPPORTED,
+                    "WS_FLAG_REFERENCE_ORDER is a validation mode of the test-only build (tests/libwsfluid_refcheck.so)");
+#endif
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

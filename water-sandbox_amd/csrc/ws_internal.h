@@ -215,10 +215,17 @@ void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, cons
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
 void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
-// reference-order mode
+// reference-order validation mode: compiled only into the test-only build (-DWS_WITH_REFCHECK, ws_refcheck.inc).
+// The product library refuses WS_FLAG_REFERENCE_ORDER in ws_create, so the stubs below are never reached.
+#ifdef WS_WITH_REFCHECK
 void wsk_ref_step(hipStream_t s, const WsDev &d, WsRef r);
 void wsk_ref_load(hipStream_t s, const ws_particle80 *in_dev, WsRef r, uint32_t n, bool reset_index);
 void wsk_ref_store(hipStream_t s, const WsDev &d, WsRef r, ws_particle80 *out_dev, uint32_t n);
+#else
+inline void wsk_ref_step(hipStream_t, const WsDev &, WsRef) {}
+inline void wsk_ref_load(hipStream_t, const ws_particle80 *, WsRef, uint32_t, bool) {}
+inline void wsk_ref_store(hipStream_t, const WsDev &, WsRef, ws_particle80 *, uint32_t) {}
+#endif
 // slabs
 void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
                       uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR);

@@ -443,14 +443,27 @@ __device__ __forceinline__ float sk_visc(const WsDev &d, float dst)
 
 // How many of the 27 stencil offsets of the reference's hashed table land on the
 // bucket of a neighbour whose true cell differs by (dx,dy,dz): 1 for every N where no
-// two stencil cells alias (all the benchmark sizes), more for tiny N.
+// two stencil cells alias (all the benchmark sizes), more for tiny N.  For a power-of-two N
+// hash_cell is linear mod N and the count depends on the cell difference only (27-entry table);
+// for any other N the `% N` after the 2^32 wrap makes it depend on the cell itself, and the
+// count is taken literally: the stencil offsets o of a's cell with hash(cell_a + o) == hash(cell_b).
 __device__ __forceinline__ uint32_t alias_mult(const WsDev &d, const uint8_t *__restrict__ mult, float4 a, float4 b)
 {
-    const int dx = (int)(floorf(b.x / d.h) - floorf(a.x / d.h));
-    const int dy = (int)(floorf(b.y / d.h) - floorf(a.y / d.h));
-    const int dz = (int)(floorf(b.z / d.h) - floorf(a.z / d.h));
+    const int ax = (int)floorf(a.x / d.h), ay = (int)floorf(a.y / d.h), az = (int)floorf(a.z / d.h);
+    const int bx = (int)floorf(b.x / d.h), by = (int)floorf(b.y / d.h), bz = (int)floorf(b.z / d.h);
+    const int dx = bx - ax, dy = by - ay, dz = bz - az;
     if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) return 0u;
-    return mult[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)];
+    if ((d.hash_n & (d.hash_n - 1u)) == 0u) return mult[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)];
+    const uint32_t hb = ((uint32_t)bx * 15823u + (uint32_t)by * 9737333u + (uint32_t)bz * 440817757u) % d.hash_n;
+    uint32_t cnt = 0;
+    for (int ox = -1; ox <= 1; ox++)
+        for (int oy = -1; oy <= 1; oy++)
+            for (int oz = -1; oz <= 1; oz++) {
+                const uint32_t ho = ((uint32_t)(ax + ox) * 15823u + (uint32_t)(ay + oy) * 9737333u +
+                                     (uint32_t)(az + oz) * 440817757u) % d.hash_n;
+                cnt += ho == hb ? 1u : 0u;
+            }
+    return cnt;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1312,185 +1325,10 @@ void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_
 }
 
 // ---------------------------------------------------------------------------------
-// Reference-order mode (WS_FLAG_REFERENCE_ORDER): the reference's six passes executed literally --
-// N-bucket hashed table, the bitonic network on the persisted permutation, atomicMin cell offsets,
-// bucket walks in OFFSET_TABLE order -- over arrays indexed by particle id, with the same IEEE
-// arithmetic as everywhere else in this file.  A validation mode: it reproduces the reference's
-// summation order, hence (against the oracle's exact mode) every float bit for bit; it is not the
-// fast path and is never benchmarked as such.
+// The reference-order validation kernels (a literal HIP restatement of the six WGSL entry points, used only to
+// cross-check the CPU restatement bit for bit) are NOT part of the product library: they live in ws_refcheck.inc and are
+// compiled only into the test-only build (tests/libwsfluid_refcheck.so, -DWS_WITH_REFCHECK).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ref_hash3(int cx, int cy, int cz, uint32_t n)
-{
-    return ((uint32_t)cx * 15823u + (uint32_t)cy * 9737333u + (uint32_t)cz * 440817757u) % n;
-}
-
-// K1 hash_particles, simulation.wgsl:130-141
-__global__ void __launch_bounds__(WS_BLOCK) kr_hash(WsDev d, WsRef r)
-{
-    const uint32_t index = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (index >= d.n) return;
-    r.offs[index] = 999999999u;
-    const uint32_t pid = r.perm[index];
-    const float4 p = r.pred[pid];
-    r.keys[pid] = ref_hash_key(d, p.x, p.y, p.z);
-}
-
-// K2 bitonic_sort, bitonic_sort.wgsl:22-46 (one compare-exchange stage)
-__global__ void __launch_bounds__(WS_BLOCK) kr_bitonic(uint32_t n, uint32_t block, uint32_t dim, WsRef r)
-{
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    const uint32_t j = i ^ block;
-    if (j < i || i >= n || j >= n) return;
-    const int sign = (i & dim) != 0 ? -1 : 1;
-    const uint32_t key_i = r.perm[i], key_j = r.perm[j];
-    const uint32_t value_i = r.keys[key_i], value_j = r.keys[key_j];
-    const int diff = (int)(value_i - value_j) * sign;
-    if (diff > 0) {
-        r.perm[i] = key_j;
-        r.perm[j] = key_i;
-    }
-}
-
-// K3 calculate_cell_offsets, bitonic_sort.wgsl:48-59
-__global__ void __launch_bounds__(WS_BLOCK) kr_offsets(WsDev d, WsRef r)
-{
-    const uint32_t index = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (index >= d.n) return;
-    atomicMin(&r.offs[r.keys[r.perm[index]]], index);
-}
-
-// K4 update_density, simulation.wgsl:143-195
-__global__ void __launch_bounds__(WS_BLOCK) kr_density(WsDev d, WsRef r)
-{
-    const uint32_t index = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (index >= d.n) return;
-    const uint32_t pid = r.perm[index];
-    const float4 o = r.pred[pid];
-    const int cx = (int)floorf(o.x / d.h), cy = (int)floorf(o.y / d.h), cz = (int)floorf(o.z / d.h);
-    float density = 0.f, near_density = 0.f;
-    for (int t = 0; t < 27; t++) {  // OFFSET_TABLE order: x slowest, z fastest
-        const uint32_t hash_index = ref_hash3(cx + t / 9 - 1, cy + (t / 3) % 3 - 1, cz + t % 3 - 1, d.hash_n);
-        uint32_t it = r.offs[hash_index];
-        while (it < d.n) {
-            const uint32_t nb = r.perm[it];
-            if (r.keys[nb] != hash_index) break;
-            it++;
-            const float4 q = r.pred[nb];
-            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-            const float d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 > d.d2_accept) continue;
-            density_pair<true>(d, d2, density, near_density, 1u);
-        }
-    }
-    r.dens[pid] = make_float2(density + 0.00001f, near_density + 0.00001f);
-}
-
-// K5 update_pressure_force, simulation.wgsl:197-269
-__global__ void __launch_bounds__(WS_BLOCK) kr_force(WsDev d, WsRef r)
-{
-    const uint32_t index = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (index >= d.n) return;
-    const uint32_t pid = r.perm[index];
-    const float4 o = r.pred[pid], vel = r.vel[pid];
-    const float2 rho = r.dens[pid];
-    const float pressure = d.pressure_scalar * (rho.x - d.target_density);
-    const float near_pressure = d.near_pressure_scalar * rho.y;
-    const int cx = (int)floorf(o.x / d.h), cy = (int)floorf(o.y / d.h), cz = (int)floorf(o.z / d.h);
-    ForceAcc a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < 27; t++) {
-        const uint32_t hash_index = ref_hash3(cx + t / 9 - 1, cy + (t / 3) % 3 - 1, cz + t % 3 - 1, d.hash_n);
-        uint32_t it = r.offs[hash_index];
-        while (it < d.n) {
-            const uint32_t nb = r.perm[it];
-            if (r.keys[nb] != hash_index) break;
-            it++;
-            if (pid == nb) continue;
-            const float4 q = r.pred[nb];
-            const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
-            const float d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 > d.d2_accept) continue;
-            const float2 nrho = r.dens[nb];
-            force_pair<true>(d, ex, ey, ez, d2, nrho.x, nrho.y, r.vel[nb], vel, pressure, near_pressure, a, 1u);
-        }
-    }
-    r.acc[pid] = make_float4(a.pfx / rho.x + a.vfx * d.viscosity, a.pfy / rho.x + a.vfy * d.viscosity,
-                             a.pfz / rho.x + a.vfz * d.viscosity, 0.f);
-}
-
-// K6 integrate, simulation.wgsl:271-310 (by particle id)
-__global__ void __launch_bounds__(WS_BLOCK) kr_integrate(WsDev d, WsRef r)
-{
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
-    const float4 v0 = r.vel[i], a = r.acc[i], p0 = r.pos[i];
-    float vx = v0.x + (d.grav[0] + a.x) * d.dt, vy = v0.y + (d.grav[1] + a.y) * d.dt, vz = v0.z + (d.grav[2] + a.z) * d.dt;
-    float px = p0.x + vx * d.dt, py = p0.y + vy * d.dt, pz = p0.z + vz * d.dt;
-    const float nd = -1.f * d.damping;
-    if (px < d.ext_min[0]) { vx *= nd; px = d.ext_min[0]; } else if (px > d.ext_max[0]) { vx *= nd; px = d.ext_max[0]; }
-    if (py < d.ext_min[1]) { vy *= nd; py = d.ext_min[1]; } else if (py > d.ext_max[1]) { vy *= nd; py = d.ext_max[1]; }
-    if (pz < d.ext_min[2]) { vz *= nd; pz = d.ext_min[2]; } else if (pz > d.ext_max[2]) { vz *= nd; pz = d.ext_max[2]; }
-    r.vel[i] = make_float4(vx, vy, vz, 0.f);
-    r.pos[i] = make_float4(px, py, pz, 0.f);
-    r.pred[i] = make_float4(px + vx * 0.02f, py + vy * 0.02f, pz + vz * 0.02f, 0.f);
-}
-
-void wsk_ref_step(hipStream_t s, const WsDev &d, WsRef r)
-{
-    const dim3 g(cdiv(d.n, WS_BLOCK)), b(WS_BLOCK);
-    hipLaunchKernelGGL(kr_hash, g, b, 0, s, d, r);
-    uint64_t p = 1;
-    while (p < d.n) p <<= 1;
-    // src/fluid_compute.rs:256-271: dim = 2, 4, .., P; block = dim/2, .., 1 -- one dispatch per stage
-    for (uint64_t dim = 2; dim <= p; dim <<= 1)
-        for (uint64_t block = dim >> 1; block > 0; block >>= 1)
-            hipLaunchKernelGGL(kr_bitonic, g, b, 0, s, d.n, (uint32_t)block, (uint32_t)dim, r);
-    hipLaunchKernelGGL(kr_offsets, g, b, 0, s, d, r);
-    hipLaunchKernelGGL(kr_density, g, b, 0, s, d, r);
-    hipLaunchKernelGGL(kr_force, g, b, 0, s, d, r);
-    hipLaunchKernelGGL(kr_integrate, g, b, 0, s, d, r);
-}
-
-// state in / out of the reference-order arrays
-__global__ void __launch_bounds__(WS_BLOCK) kr_load(const ws_particle80 *__restrict__ in, WsRef r, uint32_t n, int reset_index)
-{
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float4 *rec = reinterpret_cast<const float4 *>(in + i);
-    const float4 p = rec[0], dp = rec[1], v = rec[2], a = rec[3], q = rec[4];
-    r.pos[i] = make_float4(p.x, p.y, p.z, 0.f);
-    r.dens[i] = make_float2(dp.x, dp.y);
-    r.vel[i] = make_float4(v.x, v.y, v.z, 0.f);
-    r.acc[i] = make_float4(a.x, a.y, a.z, 0.f);
-    r.pred[i] = make_float4(q.x, q.y, q.z, 0.f);
-    if (reset_index) {  // src/fluid_compute.rs:306-308,:522-524: identity
-        r.perm[i] = i;
-        r.keys[i] = i;
-        r.offs[i] = i;
-    }
-}
-
-__global__ void __launch_bounds__(WS_BLOCK) kr_store(WsDev d, WsRef r, ws_particle80 *__restrict__ out, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float2 rho = r.dens[i];
-    float4 *rec = reinterpret_cast<float4 *>(out + i);
-    rec[0] = r.pos[i];
-    // the reference stores pressure in K4 (simulation.wgsl:192-193); 0 before the first step
-    const bool stepped = rho.x != 0.f || rho.y != 0.f;
-    rec[1] = make_float4(rho.x, rho.y, stepped ? d.pressure_scalar * (rho.x - d.target_density) : 0.f,
-                         stepped ? d.near_pressure_scalar * rho.y : 0.f);
-    rec[2] = r.vel[i];
-    rec[3] = r.acc[i];
-    rec[4] = r.pred[i];
-}
-
-void wsk_ref_load(hipStream_t s, const ws_particle80 *in_dev, WsRef r, uint32_t n, bool reset_index)
-{
-    hipLaunchKernelGGL(kr_load, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, in_dev, r, n, reset_index ? 1 : 0);
-}
-
-void wsk_ref_store(hipStream_t s, const WsDev &d, WsRef r, ws_particle80 *out_dev, uint32_t n)
-{
-    hipLaunchKernelGGL(kr_store, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, r, out_dev, n);
-}
+#ifdef WS_WITH_REFCHECK
+#include "ws_refcheck.inc"
+#endif

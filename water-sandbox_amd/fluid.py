@@ -102,6 +102,13 @@ def load_library():
         if _build.needs_build():
             _build.build_library()
         path = _build.LIB
+    _lib = bind_library(path)
+    return _lib
+
+
+def bind_library(path):
+    """dlopen a build of the wsfluid ABI and declare its prototypes (the product library, or the test-only
+    reference-order build the tests load explicitly)."""
     L = C.CDLL(path)
     vp, u32, fp = C.c_void_p, C.c_uint32, C.POINTER(C.c_float)
     L.ws_default_params.argtypes = [C.POINTER(WsParams)]
@@ -142,7 +149,6 @@ def load_library():
     L.ws_profile_select.argtypes = [vp, u32]
     L.ws_grid_dims.argtypes = [vp, vp]
     L.ws_read_stats.argtypes = [vp, vp]
-    _lib = L
     return L
 
 
@@ -200,8 +206,9 @@ class FluidWorker:
     device buffers, `run()` enqueues one step, `ready()` polls, `read_vec("particles")`
     returns the 80-byte records in original-id order."""
 
-    def __init__(self, positions, params=None, device=0, profile=False, reference_order=False, ieee_division=False):
-        self._L = load_library()
+    def __init__(self, positions, params=None, device=0, profile=False, reference_order=False, ieee_division=False,
+                 library=None):
+        self._L = library if library is not None else load_library()
         self._h = C.c_void_p()
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
         self.n = positions.shape[0]

@@ -1,7 +1,7 @@
 // fluid_compute.hpp -- header-only C++17 mirror of the reference's fluid host interface
 // (src/fluid_compute.rs, src/fluid_container.rs, src/gravity.rs, src/helpers.rs) over the C ABI
 // of include/wsfluid.h.  The reference's host is Rust; no Rust toolchain exists in this image, so
-// this is the compiled host side that is built and exercised here (rust/fluid_hip.rs is the
+// this is the compiled host side that is built and exercised here (rust/fluid_compute.rs is the
 // source-only Bevy shim).  Names and argument meaning follow the reference.
 #pragma once
 

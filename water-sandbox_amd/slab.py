@@ -187,16 +187,13 @@ class NativeRcclTransport:
             self._L.ws_rccl_transport_destroy(C.byref(self.struct))
 
 
-def make_dist_workload(ws, config, dist_name, rank, world, chunk=1 << 22):
-    """The N-GPU benchmark workload: the single-GPU config replicated `world` times along x (lattice
-    block (ni * world) x nj x nk, container (sx * world) x sy x sz), and this rank's share of it.
-    Returns (positions_local, ids_local, n_global, params).  Generated in chunks so that no rank ever
-    holds all N x 4 M positions at once."""
+def make_dist_workload(ws, block, size, dist_name, rank, world, seed=0, chunk=1 << 22):
+    """This rank's share of an N-GPU benchmark workload: lattice block `block` (ni, nj, nk) or a uniform cloud of
+    ni * nj * nk particles (counter-based generator, `seed`) in a container of `size`, cut into `world` x-slabs.
+    Returns (positions_local, ids_local, n_global, params).  Generated in chunks so that no rank ever holds all
+    positions at once; the cloud is bit-identical to workloads.uniform_cloud of the whole domain."""
     from . import workloads
 
-    block, size = workloads.CONFIGS[config]
-    block = (block[0] * world, block[1], block[2])
-    size = (size[0] * world, size[1], size[2])
     params = fluid.make_params(container_size=size)
     n_global = block[0] * block[1] * block[2]
     pos_parts, id_parts = [], []
@@ -216,7 +213,6 @@ def make_dist_workload(ws, config, dist_name, rank, world, chunk=1 << 22):
             own = assign(params, sub, world) == rank
             pos_parts.append(sub[own]); id_parts.append(ids[own])
     else:
-        seed = workloads.cloud_seed(config)
         for s0 in range(0, n_global, chunk):
             m = min(chunk, n_global - s0)
             sub = workloads.uniform_cloud(m, seed, list(params.ext_min), list(params.ext_max), start=s0)
