@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "ws_internal.h"
@@ -20,6 +21,7 @@ thread_local std::string g_create_error;
 
 void slab_free(ws_handle *h);          // ws_slab.inc
 ws_status slab_step(ws_handle *h);     // ws_slab.inc
+ws_status slab_settle(ws_handle *h);   // ws_slab.inc
 ws_status ref_upload_positions(ws_handle *h, const float *pos_xyz);
 
 ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
@@ -659,6 +661,11 @@ ws_status ws_sync(ws_handle *h)
 {
     if (!h) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) {  // also the communication stream, and the device-side error bits of every rank seen so far
+        const ws_status st = slab_settle(h);
+        drain_profile(h);
+        return st;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     drain_profile(h);
     return WS_OK;
@@ -902,7 +909,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     // the predicted positions the last step started from live in the sorted copy
     wsk_view_keys(s, h->dev, h->srt, h->v_keys, h->v_count);
     wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, &h->v_scan_launches, n, false, 0);
-    wsk_scatter(s, h->v_keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n);
+    wsk_scatter(s, h->v_keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n, nullptr);
     wsk_view_fix(s, h->v_tmp, h->v_keys, h->v_start, h->v_perm, n);
     wsk_view_offsets(s, h->v_start, h->v_off, n);
     HIP_TRY(h, hipGetLastError());

@@ -30,7 +30,38 @@ struct WsDev {
     int32_t xoff;    // global x index of local layer 0 (0 on one GPU)
     uint32_t ncells;
     uint32_t hash_n;  // the reference's `num_particles` in hash_cell (global N)
+    // Slab handles only (nullptr / 0 on a single-GPU handle).  A slab's owned count changes with migration and is
+    // known on the device alone: kernels are launched over `n` = a host-side UPPER BOUND and read the real count
+    // from dyn[DY_N]; the density / force kernels cover the part of the owned range that range_sel names, resolved
+    // on the device from the cell starts at lidx (ws_kernels.hip ws_range).
+    const uint32_t *dyn;
+    uint32_t range_sel;            // WS_RANGE_*
+    uint32_t has_left, has_right;  // x-neighbours present
+    uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
 };
+
+// words of the device block `dyn` of a slab handle
+enum {
+    DY_N = 0,        // owned particles
+    DY_NHOLE,        // leavers of the step being migrated (all routes)
+    DY_LEAVE_L,      // ... by route: to the left neighbour, to the right neighbour, anywhere else
+    DY_LEAVE_R,
+    DY_LEAVE_FAR,
+    DY_GL,           // ghosts staged in front of / behind the owned range
+    DY_GR,
+    DY_ERR,          // sticky WS_DYN_ERR_* bits
+    DY_LEFT,         // cumulative: particles that left / arrived
+    DY_ARRIVED,
+    WS_DYN_WORDS = 16
+};
+enum {
+    WS_DYN_ERR_MIGRATION = 1u,  // more leavers than a migration message holds
+    WS_DYN_ERR_CAPACITY = 2u,   // owned count would exceed the slab's capacity
+    WS_DYN_ERR_HALO = 4u,       // a boundary layer holds more particles than a halo message
+    WS_DYN_ERR_GHOSTS = 8u      // more ghosts than the ghost range holds
+};
+enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LATE_RIGHT = 3 };
+#define WS_HDR_WORDS_HOST 4u  // words of a message header (ws_kernels.hip WS_HDR_WORDS)
 
 // density / force kernel family (WS_VARIANT=simple in the environment, for A/B tests)
 enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_LISTED = 2 };
@@ -163,26 +194,33 @@ struct WsSlab {
     ws_transport tr{};
     uint32_t rank = 0, world = 1;
     uint32_t n_global = 0;
-    uint32_t cap = 0, gl_cap = 0, gr_cap = 0, mig_cap = 0;
+    // fixed capacities, known to both ends of every message
+    uint32_t cap = 0;        // owned particles
+    uint32_t halo_cap = 0;   // particles of one boundary layer = ghosts per side = records of a halo message
+    uint32_t mig_cap = 0;    // records of a neighbour migration message
+    uint32_t far_cap = 0;    // records of the all-gathered message for particles that cross several slabs
+    uint32_t hole_cap = 0;   // leavers per step (all routes)
+    uint32_t max_arrivals = 0;
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
     uint32_t *cuts_dev = nullptr;
-    uint32_t *cnt_dev = nullptr;      // [1] leavers, [2..2+world) leavers per rank, then target / source list lengths
-    uint32_t *matrix_dev = nullptr;   // all-gathered leavers-per-destination rows (world x world)
+    uint32_t *dyn = nullptr;          // WS_DYN_WORDS device words (DY_*)
     uint32_t *hole = nullptr, *tgt = nullptr, *src = nullptr;  // migration index lists
-    uint32_t *bnd_dev = nullptr, *bnd_all = nullptr;           // boundary-layer start values (4 per rank)
+    uint32_t *mig_sendL = nullptr, *mig_sendR = nullptr, *mig_recvL = nullptr, *mig_recvR = nullptr;
+    uint32_t *far_send = nullptr, *far_all = nullptr;
+    uint32_t *halo_sendL = nullptr, *halo_sendR = nullptr, *halo_recvL = nullptr, *halo_recvR = nullptr;
     bool binned = false;              // cid_cur / count describe the current owned set
-    float4 *mig_send = nullptr, *mig_all = nullptr;
-    uint32_t *tmpL = nullptr, *tmpR = nullptr;
-    uint32_t *host_pin = nullptr;     // pinned: migration matrix [W*W], then the boundary table [4W]
-    hipEvent_t ev_mark = nullptr, ev_bnd = nullptr;  // their copies have landed
-    bool mark_pending = false;        // slab_mark already enqueued for the next step
+    // what the host knows about the device state, two steps late
+    uint32_t *status_dev = nullptr, *status_host = nullptr;  // ring of per-rank header rows (pinned on the host)
+    hipEvent_t ev_status[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n_known = 0;             // owned count as of step n_known_step
+    uint64_t n_known_step = 0;
+    uint32_t failed = 0;              // sticky WS_DYN_ERR_* bits seen on any rank
     // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute
-    hipStream_t comm = nullptr;
-    hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr;
-    bool overlap = false;             // WS_SLAB_OVERLAP=1 turns it on (off until it has been measured on a multi-GPU node)
-    uint32_t gL = 0, gR = 0;          // ghosts currently staged in front of / behind the owned range
-    // cumulative statistics
-    uint64_t migrated_out = 0, ghosts_in = 0;
+    hipStream_t comm = nullptr, copy = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr, ev_filled = nullptr;
+    bool overlap = true;              // WS_SLAB_OVERLAP=0 turns it off
+    // cumulative statistics (refreshed by ws_slab_read_particles)
+    uint64_t migrated_out = 0;
 };
 
 // ---- kernel launchers (ws_kernels.hip) -------------------------------------------
@@ -195,10 +233,9 @@ void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cu
               uint32_t nitems, bool zero_count, uint32_t base);
 uint32_t wsk_scan_state_words(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
-                 uint32_t *id_tmp, uint32_t n);
+                 uint32_t *id_tmp, uint32_t n, const uint32_t *n_dev);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
                  const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz);
-void wsk_unpack_xyz(hipStream_t s, WsSorted srt, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz);
 uint32_t wsk_mask_words(void);
@@ -227,16 +264,17 @@ inline void wsk_ref_load(hipStream_t, const ws_particle80 *, WsRef, uint32_t, bo
 inline void wsk_ref_store(hipStream_t, const WsDev &, WsRef, ws_particle80 *, uint32_t) {}
 #endif
 // slabs
-void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
-                      uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR);
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
-                      uint32_t *cid_cur, uint32_t *count, uint32_t *cnt, uint32_t *hole, float4 *mig_send,
-                      uint32_t mig_cap);
-void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t n_old, uint32_t n_new, uint32_t nleave, uint32_t narrive,
-                      const uint32_t *hole, const float4 *mig_all, uint32_t world, uint32_t seg_records,
-                      const uint32_t *leave_matrix, uint32_t me, uint32_t *tgt, uint32_t *src, uint32_t *cnt, WsSoA cur,
-                      uint32_t *cid_cur, uint32_t *count);
-void wsk_pick4(hipStream_t s, const uint32_t *start, const uint32_t idx[4], uint32_t *out);
+                      uint32_t *cid_cur, uint32_t *count, uint32_t *dyn, uint32_t *hole, uint32_t hole_cap, uint32_t *sendL,
+                      uint32_t *sendR, uint32_t mig_cap, uint32_t *far, uint32_t far_cap, uint32_t step);
+void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
+                      const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
+                      const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
+                      uint32_t *count, uint32_t *status);
+void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
+                   uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities, uint32_t step);
+void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,
+                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities);
 void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids);
 void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);

@@ -63,6 +63,42 @@ __device__ __forceinline__ uint32_t ref_hash_key(const WsDev &d, float x, float 
 }
 
 // ---------------------------------------------------------------------------------
+// particle counts and ranges that only the device knows (slab handles; see WsDev::dyn)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ws_n(const WsDev &d) { return d.dyn ? d.dyn[DY_N] : d.n; }
+
+// The part [lo, lo + len) of the sorted order a density / force launch covers.  Single-GPU handle: all of it.
+// Slab handle: the owned range, or one of the three pieces the halo / compute overlap cuts it into -- x is the
+// slowest axis of the sort, so "the owned layer next to a neighbour slab" is a contiguous range delimited by cell
+// starts: EARLY = the particles whose searches touch no ghost layer, LATE_LEFT / LATE_RIGHT = layers 1 / nxl-2.
+__device__ __forceinline__ void ws_range(const WsDev &d, const uint32_t *__restrict__ start, uint32_t &lo, uint32_t &len)
+{
+    if (!d.dyn) {
+        lo = d.base;
+        len = d.n;
+        return;
+    }
+    const uint32_t n = d.dyn[DY_N], end = d.base + n;
+    if (d.range_sel == WS_RANGE_ALL) {
+        lo = d.base;
+        len = n;
+        return;
+    }
+    const uint32_t a = d.has_left ? start[d.lidx[1]] : d.base;  // first particle that needs no left ghosts
+    const uint32_t b = d.has_right ? start[d.lidx[2]] : end;     // first particle of the right boundary layer
+    if (d.range_sel == WS_RANGE_EARLY) {
+        lo = a;
+        len = b - a;
+    } else if (d.range_sel == WS_RANGE_LATE_LEFT) {
+        lo = d.base;
+        len = a - d.base;
+    } else {
+        lo = b;
+        len = end - b;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // uploads
 // ---------------------------------------------------------------------------------
 
@@ -107,7 +143,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_bin(WsDev d, const float4 *__restr
                                                   uint32_t *__restrict__ rank)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
+    if (i >= ws_n(d)) return;
     const float4 p = pred[i];
     const uint32_t c = grid_cell(d, p.x, p.y, p.z);
     cid[i] = c;
@@ -316,10 +352,11 @@ void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cu
 __global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict__ keys,
                                                       const float4 *__restrict__ pos_with_id,
                                                       uint32_t *__restrict__ cursor, uint32_t *__restrict__ slot_tmp,
-                                                      uint32_t *__restrict__ id_tmp, uint32_t n)
+                                                      uint32_t *__restrict__ id_tmp, uint32_t n,
+                                                      const uint32_t *__restrict__ n_dev)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    const bool active = i < n;
+    const bool active = i < (n_dev ? *n_dev : n);  // slab handles: n is an upper bound, the count lives on the device
     const uint32_t slot = wave_run_atomic_inc(cursor, active ? keys[i] : 0u, active);
     if (!active) return;
     slot_tmp[slot] = i;
@@ -349,10 +386,10 @@ void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_
 }
 
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
-                 uint32_t *id_tmp, uint32_t n)
+                 uint32_t *id_tmp, uint32_t n, const uint32_t *n_dev)
 {
     hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, keys, pos_with_id, cursor, slot_tmp,
-                       id_tmp, n);
+                       id_tmp, n, n_dev);
 }
 
 // `cur` and cid_cur are indexed from the first owned particle (the caller passes offset pointers);
@@ -364,7 +401,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
                                                       uint32_t *__restrict__ cid_srt, WsXYZ sxyz)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (k >= d.n) return;
+    if (k >= ws_n(d)) return;
     const uint32_t s = d.base + k;
     const uint32_t i = slot_tmp[s];
     const uint32_t id = id_tmp[s];
@@ -395,25 +432,6 @@ void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const 
 {
     hipLaunchKernelGGL(k_reorder, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur, start,
                        cur, srt, cid_srt, sxyz);
-}
-
-// slabs: planar copy of the ghost layers' predicted positions after halo A ([lo0, hi0) and [lo1, hi1))
-__global__ void __launch_bounds__(WS_BLOCK) k_unpack_xyz(WsSorted srt, WsXYZ sxyz, uint32_t lo0,
-                                                         uint32_t n0, uint32_t lo1, uint32_t n1)
-{
-    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (t >= n0 + n1) return;
-    const uint32_t i = t < n0 ? lo0 + t : lo1 + (t - n0);
-    const float4 q = srt.pred(i);
-    sxyz.x[i] = q.x;
-    sxyz.y[i] = q.y;
-    sxyz.z[i] = q.z;
-}
-
-void wsk_unpack_xyz(hipStream_t s, WsSorted srt, WsXYZ sxyz, uint32_t lo0, uint32_t n0, uint32_t lo1, uint32_t n1)
-{
-    if (n0 + n1 == 0) return;
-    hipLaunchKernelGGL(k_unpack_xyz, dim3(cdiv(n0 + n1, WS_BLOCK)), dim3(WS_BLOCK), 0, s, srt, sxyz, lo0, n0, lo1, n1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -647,8 +665,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint
                                                              const uint32_t *__restrict__ cid_srt, WsSorted srt,
                                                              const uint8_t *__restrict__ mult)
 {
-    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.base + d.n) return;
+    uint32_t lo, len;
+    ws_range(d, start, lo, len);
+    const uint32_t i = lo + blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= lo + len) return;
     float density = 0.f, near_density = 0.f;
     density_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, srt.pred(i), (int)cid_srt[i], density, near_density);
     density_store(density, near_density, i, srt);
@@ -660,8 +680,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
                                                            float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                            uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
 {
-    const uint32_t i = d.base + blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.base + d.n) return;
+    uint32_t lo, len;
+    ws_range(d, start, lo, len);
+    const uint32_t i = lo + blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i >= lo + len) return;
     const float4 o = srt.pred(i);    // w = own density
     const float4 vel = srt.vel(i);   // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
@@ -707,6 +729,23 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 #define ND_ROWS (ND_K + 3) // a trip of 4 candidates may start at fill level K-1
 #define ND_MASK_WORDS 64   // 2048 candidates per particle (256 B of mask rows each; only the words in use are touched)
 
+// Workgroup -> tile map of the two neighbour kernels.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
+// share one), each with its own L2: tile = f(b) gives every XCD one CONTIGUOUS eighth of the sorted order (an
+// x-slab of the domain), so a tile's neighbour records are fetched into one L2 instead of into all eight.
+// Speed / traffic only: any placement computes the same thing.
+#ifndef WS_XCD_TILES
+#define WS_XCD_TILES 1
+#endif
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nt)
+{
+#if WS_XCD_TILES
+    const uint32_t xcd = b & 7u, q = nt >> 3, r = nt & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
+#else
+    return b;
+#endif
+}
+
 typedef float nd_f4 __attribute__((ext_vector_type(4)));
 typedef float nd_f4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive floats, 4-byte aligned
 
@@ -751,9 +790,13 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
                                                          WsMask mask, uint32_t *__restrict__ stats)
 {
     __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
-    const uint32_t i = d.base + blockIdx.x * ND_P + threadIdx.x;
-    const bool valid = i < d.base + d.n;
-    const uint32_t iv = valid ? i : d.base + d.n - 1u;
+    uint32_t lo, len;
+    ws_range(d, start, lo, len);
+    const uint32_t ntiles = (len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t i = lo + xcd_tile(blockIdx.x, ntiles) * ND_P + threadIdx.x;
+    const bool valid = i < lo + len;
+    const uint32_t iv = valid ? i : lo + len - 1u;
     const float4 o = make_float4(sxyz.x[iv], sxyz.y[iv], sxyz.z[iv], 0.f);  // the planar copy: coalesced, same bits
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
@@ -812,9 +855,13 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     // per-lane run table: candidate numbers [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
     __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
     __shared__ uint32_t t_delta[9 * NF_P];
-    const uint32_t i = d.base + blockIdx.x * NF_P + threadIdx.x;
-    const bool valid = i < d.base + d.n;
-    const uint32_t iv = valid ? i : d.base + d.n - 1u;
+    uint32_t lo, len;
+    ws_range(d, start, lo, len);
+    const uint32_t ntiles = (len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t i = lo + xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
+    const bool valid = i < lo + len;
+    const uint32_t iv = valid ? i : lo + len - 1u;
     const float4 o = srt.pred(iv);   // w = own density
     const float4 vel = srt.vel(iv);  // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
@@ -1090,58 +1137,32 @@ void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n)
 
 // ---------------------------------------------------------------------------------
 // slab (multi-GPU) support kernels
+//
+// Nothing a slab step needs from the device ever goes through the host: the owned count, the boundary-layer
+// ranges, the ghost counts and the migration counts live in a small device block (`dyn`, WsDyn words) and in the
+// headers of fixed-capacity messages; kernels are launched over host-known UPPER BOUNDS and read the real
+// numbers from there.  Every capacity overrun clamps (so nothing is written out of bounds) and sets a sticky bit
+// in dyn[DY_ERR], which travels to every rank with the next step's all-gather and fails ws_step on all of them.
 // ---------------------------------------------------------------------------------
-
-// After the halo exchange: cell starts of the two ghost layers (from the neighbours' start slices,
-// rebased onto this slab's ghost slots) plus the guard entries in front of / behind the table.
-//   layer 0      <- left neighbour's last owned layer, its particles sit at [base - gL, base)
-//   layer nxl-1  <- right neighbour's first owned layer, at [base + n, base + n + gR)
-__global__ void __launch_bounds__(WS_BLOCK) k_ghost_starts(uint32_t *__restrict__ start, uint32_t guard, uint32_t rowy,
-                                                           uint32_t nxl, uint32_t base, uint32_t n, uint32_t gL,
-                                                           uint32_t gR, const uint32_t *__restrict__ tmpL,
-                                                           const uint32_t *__restrict__ tmpR)
-{
-    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
-    const uint32_t front = guard + rowy;       // guard entries + layer 0
-    const uint32_t back = rowy + guard + 2;    // layer nxl-1 + end sentinel + guard entries
-    if (t < front) {
-        uint32_t v = base - gL;
-        if (t >= guard && gL) v = base - gL + (tmpL[t - guard] - tmpL[0]);
-        if (t >= guard && !gL) v = base;
-        start[t] = v;
-    } else if (t < front + back) {
-        const uint32_t j = t - front;
-        uint32_t v = base + n + gR;
-        if (j < rowy) v = gR ? base + n + (tmpR[j] - tmpR[0]) : base + n;
-        start[guard + (nxl - 1) * rowy + j] = v;
-    }
-}
-
-void wsk_ghost_starts(hipStream_t s, uint32_t *start, uint32_t guard, uint32_t rowy, uint32_t nxl, uint32_t base,
-                      uint32_t n, uint32_t gL, uint32_t gR, const uint32_t *tmpL, const uint32_t *tmpR)
-{
-    const uint32_t total = guard + rowy + rowy + guard + 2;
-    hipLaunchKernelGGL(k_ghost_starts, dim3(cdiv(total, WS_BLOCK)), dim3(WS_BLOCK), 0, s, start, guard, rowy, nxl, base,
-                       n, gL, gR, tmpL, tmpR);
-}
-
-// Migration.  Particles stay where they are in `cur`; only the ones that left the slab (and the few
-// moved to close the holes they leave) are touched, and the cell histogram built by the force
-// kernel is corrected incrementally -- O(leavers + arrivals) work per step, not O(n).
-// cnt[1] = leavers, cnt[2 + r] = leavers for rank r, cnt[2 + world] / cnt[3 + world] = target / source
-// list lengths.  Order is free everywhere here: the sort puts each cell in canonical id order.
 #define WS_DEAD 0xFFFFFFFFu
 
-// part 1: find the leavers; write their 64-byte records {pos+id, vel, pred, destination rank}, remember
-// the holes they leave, take them out of the histogram
+// message header: 4 words in front of every fixed-capacity message
+//   [0] records in the message   [1] sender's sticky error bits   [2] sender's owned count   [3] step stamp
+#define WS_HDR_WORDS 4u
+
+// Migration, part 1: find the particles whose predicted position left the slab; write their 64-byte records
+// {pos+id, vel, pred, destination} into the message for their route (left neighbour, right neighbour, or the
+// small all-gathered "far" buffer for a particle that crosses more than one slab in a step), remember the holes
+// they leave, take them out of the histogram.  Order is free everywhere here: the sort is canonical.
 __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32_t *__restrict__ cuts, uint32_t world,
                                                            uint32_t me, WsSoA cur, uint32_t *__restrict__ cid_cur,
-                                                           uint32_t *__restrict__ count, uint32_t *__restrict__ cnt,
-                                                           uint32_t *__restrict__ hole, float4 *__restrict__ mig_send,
-                                                           uint32_t mig_cap)
+                                                           uint32_t *__restrict__ count, uint32_t *__restrict__ dyn,
+                                                           uint32_t *__restrict__ hole, uint32_t hole_cap,
+                                                           uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
+                                                           uint32_t mig_cap, uint32_t *__restrict__ far, uint32_t far_cap)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (k >= d.n) return;
+    if (k >= dyn[DY_N]) return;
     const uint32_t i = d.base + k;
     const float4 q = cur.pred[i];
     const float fx = floorf(q.x / d.h) - (float)d.org[0];
@@ -1149,127 +1170,294 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32
     uint32_t dest = 0;
     while (dest + 1 < world && gxg >= cuts[dest + 1]) dest++;
     if (dest == me) return;
-    const uint32_t s = atomicAdd(&cnt[1], 1u);
-    atomicAdd(&cnt[2 + dest], 1u);
     atomicSub(&count[cid_cur[i]], 1u);
     cid_cur[i] = WS_DEAD;
-    if (s < mig_cap) {
-        hole[s] = i;
-        mig_send[4 * (size_t)s] = cur.pos[i];
-        mig_send[4 * (size_t)s + 1] = cur.vel[i];
-        mig_send[4 * (size_t)s + 2] = q;
-        mig_send[4 * (size_t)s + 3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
+    const uint32_t hs = atomicAdd(&dyn[DY_NHOLE], 1u);
+    if (hs < hole_cap) hole[hs] = i;
+    uint32_t *msg;
+    uint32_t slot, cap;
+    if (dest + 1u == me) {
+        msg = sendL; cap = mig_cap; slot = atomicAdd(&dyn[DY_LEAVE_L], 1u);
+    } else if (dest == me + 1u) {
+        msg = sendR; cap = mig_cap; slot = atomicAdd(&dyn[DY_LEAVE_R], 1u);
+    } else {
+        msg = far; cap = far_cap; slot = atomicAdd(&dyn[DY_LEAVE_FAR], 1u);
+    }
+    if (slot >= cap) {  // the message is full: the particle is lost, the step is invalid -- say so
+        atomicOr(&dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
+        return;
+    }
+    float4 *rec = reinterpret_cast<float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)slot;
+    rec[0] = cur.pos[i];
+    rec[1] = cur.vel[i];
+    rec[2] = q;
+    rec[3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
+}
+
+// ... and the headers of the three migration messages, once the counts are final
+__global__ void k_migrate_seal(uint32_t *__restrict__ dyn, uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
+                               uint32_t mig_cap, uint32_t *__restrict__ far, uint32_t far_cap, uint32_t hole_cap,
+                               uint32_t step)
+{
+    if (threadIdx.x != 0) return;
+    if (dyn[DY_NHOLE] > hole_cap) {
+        dyn[DY_ERR] |= WS_DYN_ERR_MIGRATION;
+        dyn[DY_NHOLE] = hole_cap;
+    }
+    const uint32_t err = dyn[DY_ERR], n = dyn[DY_N];
+    uint32_t *msgs[3] = {sendL, sendR, far};
+    const uint32_t cnt[3] = {min(dyn[DY_LEAVE_L], mig_cap), min(dyn[DY_LEAVE_R], mig_cap), min(dyn[DY_LEAVE_FAR], far_cap)};
+    for (int m = 0; m < 3; m++) {
+        msgs[m][0] = cnt[m];
+        msgs[m][1] = err;
+        msgs[m][2] = n;
+        msgs[m][3] = step;
     }
 }
 
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
-                      uint32_t *cid_cur, uint32_t *count, uint32_t *cnt, uint32_t *hole, float4 *mig_send,
-                      uint32_t mig_cap)
+                      uint32_t *cid_cur, uint32_t *count, uint32_t *dyn, uint32_t *hole, uint32_t hole_cap, uint32_t *sendL,
+                      uint32_t *sendR, uint32_t mig_cap, uint32_t *far, uint32_t far_cap, uint32_t step)
 {
-    if (d.n == 0) return;
-    hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, cid_cur,
-                       count, cnt, hole, mig_send, mig_cap);
+    if (d.n)
+        hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, cid_cur,
+                           count, dyn, hole, hole_cap, sendL, sendR, mig_cap, far, far_cap);
+    hipLaunchKernelGGL(k_migrate_seal, dim3(1), dim3(64), 0, s, dyn, sendL, sendR, mig_cap, far, far_cap, hole_cap, step);
 }
 
-// part 2: the owned range shrinks / grows from n_old to n_new.  Targets = holes below n_new (+ the new
-// slots when growing); sources = this rank's arrivals in the all-gathered records (tagged with the top
-// bit) + surviving particles above n_new.  Both lists come out equally long.
-__global__ void __launch_bounds__(WS_BLOCK) k_migrate_collect(uint32_t base, uint32_t n_old, uint32_t n_new, uint32_t nleave,
-                                                              const uint32_t *__restrict__ hole,
-                                                              const uint32_t *__restrict__ cid_cur,
-                                                              const float4 *__restrict__ mig_all, uint32_t world,
-                                                              uint32_t seg_records,
-                                                              const uint32_t *__restrict__ leave_matrix, uint32_t me,
-                                                              uint32_t *__restrict__ tgt, uint32_t *__restrict__ src,
-                                                              uint32_t *__restrict__ cnt)
+// Migration, part 2 (ONE workgroup; a step moves a few thousand particles at most): count the arrivals, fix the new
+// owned count, then close the holes.  The owned range shrinks / grows from n_old to n_new.  Targets = holes below
+// n_new (+ the new slots when growing); sources = arrivals (tagged with their message in the top two bits) +
+// surviving particles above n_new.  Both lists come out equally long.  Also copies the all-gathered message headers
+// into `status` (one 4-word row per rank: the host reads it two steps later).
+#define WS_FILL_THREADS 1024
+__global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint32_t world, uint32_t me, uint32_t cap,
+                                                                 uint32_t *__restrict__ dyn, const uint32_t *__restrict__ hole,
+                                                                 const uint32_t *__restrict__ recvL,
+                                                                 const uint32_t *__restrict__ recvR, uint32_t mig_cap,
+                                                                 const uint32_t *__restrict__ far_all, uint32_t far_cap,
+                                                                 uint32_t *__restrict__ tgt, uint32_t *__restrict__ src,
+                                                                 WsSoA cur, uint32_t *__restrict__ cid_cur,
+                                                                 uint32_t *__restrict__ count, uint32_t *__restrict__ status)
 {
-    uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
-    uint32_t *n_tgt = cnt + 2 + world, *n_src = cnt + 3 + world;
-    if (t < nleave) {  // A: holes
+    __shared__ uint32_t s_far, s_ntgt, s_nsrc, s_nnew, s_nold, s_arr;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;  // words per rank in the gathered far buffer
+    const bool left = me > 0, right = me + 1 < world;
+    if (tid == 0) {
+        s_far = 0;
+        s_ntgt = 0;
+        s_nsrc = 0;
+    }
+    __syncthreads();
+    // far arrivals: records of other ranks' far messages addressed to this rank
+    for (uint32_t t = tid; t < world * far_cap; t += WS_FILL_THREADS) {
+        const uint32_t q = t / far_cap, k = t % far_cap;
+        if (q == me) continue;
+        const uint32_t *msg = far_all + (size_t)q * far_words;
+        if (k >= min(msg[0], far_cap)) continue;
+        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k;
+        if (__float_as_uint(rec[3].x) == me) atomicAdd(&s_far, 1u);
+    }
+    if (tid < world) {
+        const uint32_t *msg = far_all + (size_t)tid * far_words;
+        for (uint32_t w = 0; w < WS_HDR_WORDS; w++) status[tid * WS_HDR_WORDS + w] = msg[w];
+    }
+    __syncthreads();
+    const uint32_t nL = left ? min(recvL[0], mig_cap) : 0u, nR = right ? min(recvR[0], mig_cap) : 0u;
+    const uint32_t leave = dyn[DY_NHOLE];
+    if (tid == 0) {
+        const uint32_t n_old = dyn[DY_N];
+        uint32_t arrivals = nL + nR + s_far;
+        uint32_t n_new = n_old - leave + arrivals;
+        if (n_new > cap) {  // cannot hold them: drop the excess arrivals, flag the step
+            atomicOr(&dyn[DY_ERR], WS_DYN_ERR_CAPACITY);
+            arrivals -= n_new - cap;
+            n_new = cap;
+        }
+        s_nold = n_old;
+        s_nnew = n_new;
+        s_arr = arrivals;
+    }
+    __syncthreads();
+    const uint32_t n_old = s_nold, n_new = s_nnew, base = d.base;
+    // targets
+    for (uint32_t t = tid; t < leave; t += WS_FILL_THREADS) {
         const uint32_t i = hole[t];
-        if (i < base + n_new) tgt[atomicAdd(n_tgt, 1u)] = i;
-        return;
+        if (i < base + n_new) tgt[atomicAdd(&s_ntgt, 1u)] = i;
     }
-    t -= nleave;
-    const uint32_t tail = n_old > n_new ? n_old - n_new : 0u;
-    if (t < tail) {  // B: survivors above the new end
-        const uint32_t i = base + n_new + t;
-        if (cid_cur[i] != WS_DEAD) src[atomicAdd(n_src, 1u)] = i;
-        return;
-    }
-    t -= tail;
     const uint32_t grow = n_new > n_old ? n_new - n_old : 0u;
-    if (t < grow) {  // C: fresh slots when the owned range grows
-        tgt[atomicAdd(n_tgt, 1u)] = base + n_old + t;
+    for (uint32_t t = tid; t < grow; t += WS_FILL_THREADS) tgt[atomicAdd(&s_ntgt, 1u)] = base + n_old + t;
+    // sources
+    const uint32_t tail = n_old > n_new ? n_old - n_new : 0u;
+    for (uint32_t t = tid; t < tail; t += WS_FILL_THREADS) {
+        const uint32_t i = base + n_new + t;
+        if (cid_cur[i] != WS_DEAD) src[atomicAdd(&s_nsrc, 1u)] = i;
+    }
+    for (uint32_t t = tid; t < nL; t += WS_FILL_THREADS) src[atomicAdd(&s_nsrc, 1u)] = (1u << 30) | t;
+    for (uint32_t t = tid; t < nR; t += WS_FILL_THREADS) src[atomicAdd(&s_nsrc, 1u)] = (2u << 30) | t;
+    for (uint32_t t = tid; t < world * far_cap; t += WS_FILL_THREADS) {
+        const uint32_t q = t / far_cap, k = t % far_cap;
+        if (q == me) continue;
+        const uint32_t *msg = far_all + (size_t)q * far_words;
+        if (k >= min(msg[0], far_cap)) continue;
+        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k;
+        if (__float_as_uint(rec[3].x) == me) src[atomicAdd(&s_nsrc, 1u)] = (3u << 30) | t;
+    }
+    __syncthreads();
+    // apply: source k fills target k (any pairing will do).  After a capacity overrun there are more sources than
+    // targets and the excess is dropped.
+    const uint32_t pairs = min(s_ntgt, s_nsrc);
+    for (uint32_t t = tid; t < pairs; t += WS_FILL_THREADS) {
+        const uint32_t to = tgt[t], from = src[t];
+        const uint32_t tag = from >> 30, idx = from & 0x3FFFFFFFu;
+        if (tag) {
+            const uint32_t *msg = tag == 1u ? recvL : tag == 2u ? recvR : far_all + (size_t)(idx / far_cap) * far_words;
+            const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)(tag == 3u ? idx % far_cap : idx);
+            const float4 q = rec[2];
+            cur.pos[to] = rec[0];
+            cur.vel[to] = rec[1];
+            cur.pred[to] = q;
+            const uint32_t c = grid_cell(d, q.x, q.y, q.z);
+            cid_cur[to] = c;
+            atomicAdd(&count[c], 1u);
+        } else {
+            cur.pos[to] = cur.pos[idx];
+            cur.vel[to] = cur.vel[idx];
+            cur.pred[to] = cur.pred[idx];
+            cid_cur[to] = cid_cur[idx];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        dyn[DY_N] = n_new;
+        dyn[DY_NHOLE] = 0;
+        dyn[DY_LEAVE_L] = 0;
+        dyn[DY_LEAVE_R] = 0;
+        dyn[DY_LEAVE_FAR] = 0;
+        dyn[DY_ARRIVED] += s_arr;
+        dyn[DY_LEFT] += leave;
+    }
+}
+
+void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
+                      const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
+                      const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
+                      uint32_t *count, uint32_t *status)
+{
+    hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
+                       mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status);
+}
+
+// Halo messages.  A: [header | cell-start slice of the boundary layer (rowy + 1 words, padded to 4) | its 32-byte
+// {pred, vel} records]; B: the same particles' (density, near density), 8 bytes each.  The boundary layers are
+// contiguous ranges of the sorted order: layer 1 goes left, layer nxl - 2 goes right.
+__device__ __forceinline__ uint32_t halo_slice_words(uint32_t rowy) { return (rowy + 1u + 3u) & ~3u; }
+
+__global__ void __launch_bounds__(WS_BLOCK) k_halo_pack(WsDev d, const uint32_t *__restrict__ start, WsSorted srt,
+                                                        uint32_t *__restrict__ dyn, uint32_t rowy, uint32_t halo_cap,
+                                                        uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
+                                                        int densities, uint32_t step)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    const uint32_t side = blockIdx.y;  // 0: the left-going layer (1), 1: the right-going layer (nxl - 2)
+    uint32_t *msg = side ? sendR : sendL;
+    const uint32_t first = side ? d.lidx[2] : d.lidx[0];  // index of the layer's first cell start
+    const uint32_t s0 = start[first], cnt_all = start[first + rowy] - s0;
+    const uint32_t cnt = min(cnt_all, halo_cap);
+    if (densities) {
+        if (t < cnt) reinterpret_cast<float2 *>(msg)[t] = make_float2(srt.pred(s0 + t).w, srt.vel(s0 + t).w);
         return;
     }
-    t -= grow;
-    if (t < world * seg_records) {  // D: arrivals addressed to this rank
-        const uint32_t q = t / seg_records, k = t % seg_records;
-        if (q == me) return;
-        uint32_t lq = 0;
-        for (uint32_t r = 0; r < world; r++) lq += leave_matrix[q * world + r];
-        if (k >= lq) return;
-        if (__float_as_uint(mig_all[4 * (size_t)t + 3].x) == me) src[atomicAdd(n_src, 1u)] = 0x80000000u | t;
+    if (t == 0) {
+        if (cnt_all > halo_cap) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_HALO);
+        msg[0] = cnt;
+        msg[1] = dyn[DY_ERR];
+        msg[2] = dyn[DY_N];
+        msg[3] = step;
+    }
+    if (t <= rowy) msg[WS_HDR_WORDS + t] = start[first + t];
+    if (t < cnt) {
+        float4 *rec = reinterpret_cast<float4 *>(msg + WS_HDR_WORDS + halo_slice_words(rowy)) + 2 * (size_t)t;
+        rec[0] = srt.pred(s0 + t);
+        rec[1] = srt.vel(s0 + t);
     }
 }
 
-__global__ void __launch_bounds__(WS_BLOCK) k_migrate_apply(WsDev d, const uint32_t *__restrict__ tgt,
-                                                            const uint32_t *__restrict__ src,
-                                                            const uint32_t *__restrict__ cnt, uint32_t world, WsSoA cur,
-                                                            uint32_t *__restrict__ cid_cur, uint32_t *__restrict__ count,
-                                                            const float4 *__restrict__ mig_all)
+void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
+                   uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities, uint32_t step)
 {
-    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (k >= cnt[2 + world]) return;
-    const uint32_t to = tgt[k], from = src[k];
-    if (from & 0x80000000u) {
-        const float4 *rec = mig_all + 4 * (size_t)(from & 0x7FFFFFFFu);
-        const float4 q = rec[2];
-        cur.pos[to] = rec[0];
-        cur.vel[to] = rec[1];
-        cur.pred[to] = q;
-        const uint32_t c = grid_cell(d, q.x, q.y, q.z);
-        cid_cur[to] = c;
-        atomicAdd(&count[c], 1u);
+    const uint32_t work = densities ? halo_cap : max(halo_cap, rowy + 1u);
+    hipLaunchKernelGGL(k_halo_pack, dim3(cdiv(work, WS_BLOCK), 2), dim3(WS_BLOCK), 0, s, d, start, srt, dyn, rowy, halo_cap,
+                       sendL, sendR, densities ? 1 : 0, step);
+}
+
+// After halo A: the ghost records into [base - gL, base) and [base + n, base + n + gR), their planar copy for K4,
+// and the cell starts of the two ghost layers (the neighbours' start slices rebased onto this slab's ghost slots)
+// plus the guard entries in front of / behind the table.
+//   layer 0      <- left neighbour's last owned layer      layer nxl-1  <- right neighbour's first owned layer
+// After halo B (densities != 0): only the w lanes of the ghost records.
+__global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__restrict__ start, WsSorted srt, WsXYZ sxyz,
+                                                          uint32_t *__restrict__ dyn, uint32_t rowy, uint32_t nxl,
+                                                          uint32_t ghost_cap, const uint32_t *__restrict__ recvL,
+                                                          const uint32_t *__restrict__ recvR, int densities)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    const uint32_t side = blockIdx.y;
+    const bool have = side ? d.has_right != 0u : d.has_left != 0u;
+    const uint32_t *msg = side ? recvR : recvL;
+    const uint32_t n = dyn[DY_N], base = d.base, guard = (uint32_t)d.guard;
+    if (densities) {
+        const uint32_t g = side ? dyn[DY_GR] : dyn[DY_GL];
+        if (t < g) {
+            const uint32_t slot = side ? base + n + t : base - g + t;
+            const float2 rho = reinterpret_cast<const float2 *>(msg)[t];
+            srt.pred(slot).w = rho.x;
+            srt.vel(slot).w = rho.y;
+        }
+        return;
+    }
+    uint32_t g = have ? msg[0] : 0u;
+    if (g > ghost_cap) {
+        if (t == 0) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_GHOSTS);
+        g = ghost_cap;
+    }
+    if (t == 0) dyn[side ? DY_GR : DY_GL] = g;
+    const uint32_t *slice = msg + WS_HDR_WORDS;
+    const uint32_t first_slot = side ? base + n : base - g;
+    if (t < g) {
+        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS + halo_slice_words(rowy)) + 2 * (size_t)t;
+        const float4 q = rec[0];
+        const uint32_t slot = first_slot + t;
+        srt.pred(slot) = q;
+        srt.vel(slot) = rec[1];
+        sxyz.x[slot] = q.x;
+        sxyz.y[slot] = q.y;
+        sxyz.z[slot] = q.z;
+    }
+    if (side == 0) {
+        // guard entries + layer 0: everything in front of the owned range
+        if (t < guard + rowy) {
+            uint32_t v = base - g;
+            if (t >= guard) v = g ? base - g + min(slice[t - guard] - slice[0], g) : base;
+            start[t] = v;
+        }
     } else {
-        cur.pos[to] = cur.pos[from];
-        cur.vel[to] = cur.vel[from];
-        cur.pred[to] = cur.pred[from];
-        cid_cur[to] = cid_cur[from];
+        // layer nxl-1 + end sentinel + guard entries: everything behind the owned range
+        if (t < rowy + guard + 2u) {
+            uint32_t v = base + n + g;
+            if (t < rowy) v = g ? base + n + min(slice[t] - slice[0], g) : base + n;
+            start[guard + (nxl - 1u) * rowy + t] = v;
+        }
     }
 }
 
-void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t n_old, uint32_t n_new, uint32_t nleave, uint32_t narrive,
-                      const uint32_t *hole, const float4 *mig_all, uint32_t world, uint32_t seg_records,
-                      const uint32_t *leave_matrix, uint32_t me, uint32_t *tgt, uint32_t *src, uint32_t *cnt, WsSoA cur,
-                      uint32_t *cid_cur, uint32_t *count)
+void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,
+                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities)
 {
-    const uint32_t tail = n_old > n_new ? n_old - n_new : 0u, grow = n_new > n_old ? n_new - n_old : 0u;
-    const uint32_t total = nleave + tail + grow + (narrive ? world * seg_records : 0u);
-    if (!total) return;
-    hipLaunchKernelGGL(k_migrate_collect, dim3(cdiv(total, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d.base, n_old, n_new, nleave,
-                       hole, cid_cur, mig_all, world, narrive ? seg_records : 0u, leave_matrix, me, tgt, src, cnt);
-    const uint32_t pairs = nleave > narrive ? nleave : narrive;
-    hipLaunchKernelGGL(k_migrate_apply, dim3(cdiv(pairs, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, tgt, src, cnt, world, cur,
-                       cid_cur, count, mig_all);
-}
-
-// the four cell-start values that delimit the two boundary layers, packed for the all-gather
-__global__ void k_pick4(const uint32_t *__restrict__ start, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3,
-                        uint32_t *__restrict__ out)
-{
-    if (threadIdx.x == 0) {
-        out[0] = start[i0];
-        out[1] = start[i1];
-        out[2] = start[i2];
-        out[3] = start[i3];
-    }
-}
-
-void wsk_pick4(hipStream_t s, const uint32_t *start, const uint32_t idx[4], uint32_t *out)
-{
-    hipLaunchKernelGGL(k_pick4, dim3(1), dim3(64), 0, s, start, idx[0], idx[1], idx[2], idx[3], out);
+    const uint32_t work = densities ? ghost_cap : max(ghost_cap, rowy + (uint32_t)d.guard + 2u);
+    hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(work, WS_BLOCK), 2), dim3(WS_BLOCK), 0, s, d, start, srt, sxyz, dyn, rowy, nxl,
+                       ghost_cap, recvL, recvR, densities ? 1 : 0);
 }
 
 // Slab readback: owned particles (state of the last step, sorted order) with their ids.
@@ -1278,7 +1466,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, Ws
                                                           uint32_t *__restrict__ ids)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (k >= d.n) return;
+    if (k >= ws_n(d)) return;
     const uint32_t i = d.base + k;
     const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
