@@ -331,6 +331,8 @@ class SlabWorker:
         self._check(self._L.ws_sync(self._h))
 
     def num_owned(self):
+        """Particles this slab owns after the steps enqueued so far (the count lives on the device: waits for them)."""
+        self.sync()
         return int(self._L.ws_num_particles(self._h))
 
     def read(self):
