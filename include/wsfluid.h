@@ -90,7 +90,9 @@ typedef struct ws_device_cfg {
     uint32_t world_size;     /* number of slabs (0 or 1 = single GPU) */
     uint32_t capacity;       /* slabs: max particles this handle may own (0 = 2 n_local + 2^20);
                                 head-room for particles migrating in */
-    uint32_t ghost_capacity; /* slabs: max ghost particles per face (0 = capacity / 4 + 2^16) */
+    uint32_t ghost_capacity; /* slabs: max particles of ONE boundary layer = ghosts per face = records of a halo
+                                message, a FIXED size both neighbours know (0 = 4 n_global / nx + 2^14, nx = cell
+                                layers along x: four times an evenly spread layer) */
     uint32_t reserved[2];
     void *stream;            /* hipStream_t to enqueue on, or NULL: the library creates its own.
                                 A host that moves halos with its own communication library passes
@@ -195,15 +197,22 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  * The domain is cut into world_size slabs along x on cell boundaries (x is the slowest axis of the
  * cell grid, so a slab is a contiguous range of the global cell order and its boundary layers are
  * contiguous particle ranges).  Interactions reach one cell, so a slab needs one ghost layer from
- * each x-neighbour.  ws_step on a slab handle runs, per step:
- *   sort own particles -> send the two boundary layers' predicted positions to the neighbours
- *   (halo A) -> K4 -> send their densities (halo B) -> K5+K6 -> hand particles whose predicted
- *   position left the slab to their new owner (migration).
- * All data movement goes through the two transport callbacks below (bench.py implements them with
- * torch.distributed on the RCCL backend: send/recv with the two neighbours; small all-gathers carry
- * the per-step counts and the migrating particles).  Two host syncs per step read those counts.  The particle order inside a cell is canonical (by id), so an N-slab run
- * reproduces the single-GPU run bit for bit.  The reference has no multi-device path; this is
- * the scale-out row of SURVEY.md 8(e). */
+ * each x-neighbour.  ws_step on a slab handle enqueues, per step:
+ *   hand particles whose predicted position left the slab to their new owner (migration: one send/recv with each
+ *   neighbour, plus one small all-gather for the rare particle that crosses several slabs in a step) -> sort own
+ *   particles -> send the two boundary layers' records to the neighbours (halo A) -> K4 -> send their densities
+ *   (halo B) -> K5+K6; with the halos on a second stream while the particles that need no ghosts compute.
+ * ws_step NEVER WAITS FOR THE DEVICE on a slab handle either: every message has a fixed capacity known to both ends
+ * (ghost_capacity and sizes derived from it) and carries its record count in a header; the owned count, the layer
+ * ranges and the ghost counts stay on the device, kernels are launched over host-side upper bounds.  A capacity
+ * overrun clamps, sets a sticky error bit that reaches every rank with the next step's all-gather, and makes ws_step
+ * return WS_ERR_OUT_OF_MEMORY on ALL ranks at the same step (two steps later), before any collective of that step --
+ * no rank is left waiting in one; ws_sync / ws_slab_read_particles report it too.  ws_num_particles of a slab is
+ * exact after ws_sync.
+ * All data movement goes through the two transport callbacks below (bench.py uses the library's own RCCL
+ * transport, ws_rccl_transport_create; tests also drive them with torch.distributed and with an in-process
+ * loopback).  The particle order inside a cell is canonical (by id), so an N-slab run reproduces the single-GPU
+ * run bit for bit.  The reference has no multi-device path; this is the scale-out row of SURVEY.md 8(e). */
 typedef struct ws_transport {
     void *ctx;
     /* Stream-ordered exchange of nseg buffers with each x-neighbour, d = 0 (rank - 1) and d = 1 (rank + 1), as

@@ -25,30 +25,74 @@ def xcell(params, pred, nx_org):
     return np.floor(pred[:, 0] / H).astype(np.int64) - nx_org
 
 
-def exchange(rank, world, to_left, to_right):
-    """Send arrays to the x-neighbours, receive theirs (variable length: sizes first)."""
-    got = {}
-    for peer, payload, key in ((rank - 1, to_left, "left"), (rank + 1, to_right, "right")):
-        if not 0 <= peer < world:
-            got[key] = None
-            continue
-        size = torch.tensor([payload.shape[0]], dtype=torch.int64)
-        other = torch.zeros(1, dtype=torch.int64)
-        reqs = [dist.isend(size, peer), dist.irecv(other, peer)]
+HDR = 4  # message header words: records, sender's sticky error bits, sender's owned count, step (csrc WS_HDR_WORDS)
+ERR_MIGRATION, ERR_HALO = 1, 4
+
+
+class Protocol:
+    """The slab step's message discipline (csrc/ws_slab.inc) on gloo: every message has a FIXED capacity known to
+    both ends and carries its record count in a header; nothing is sized by a count only the sender knows.  An
+    overrun clamps and sets a sticky error bit, which reaches every rank with the per-step all-gather and is acted on
+    LAG steps later by all ranks alike."""
+    LAG = 2
+
+    def __init__(self, rank, world, halo_cap, mig_cap, far_cap):
+        self.rank, self.world = rank, world
+        self.halo_cap, self.mig_cap, self.far_cap = halo_cap, mig_cap, far_cap
+        self.err = 0
+        self.tables = {}  # step -> all ranks' headers
+
+    def _message(self, payload, cap, width, n_owned, step, errbit):
+        msg = np.zeros((1 + cap, max(width, HDR)), np.float64)
+        cnt = payload.shape[0]
+        if cnt > cap:
+            self.err |= errbit
+            cnt = cap
+        msg[0, :HDR] = (cnt, self.err, n_owned, step)
+        msg[1:1 + cnt, :width] = payload[:cnt]
+        return torch.from_numpy(msg)
+
+    def exchange(self, to_left, to_right, cap, n_owned, step, errbit):
+        """One fixed-size message to / from each x-neighbour."""
+        got = {"left": None, "right": None}
+        width = to_left.shape[1]
+        reqs, bufs = [], {}
+        for peer, payload, key in ((self.rank - 1, to_left, "left"), (self.rank + 1, to_right, "right")):
+            if not 0 <= peer < self.world:
+                continue
+            bufs[key] = torch.zeros((1 + cap, max(width, HDR)), dtype=torch.float64)
+            reqs += [dist.isend(self._message(payload, cap, width, n_owned, step, errbit), peer), dist.irecv(bufs[key], peer)]
         for r in reqs:
             r.wait()
-        buf = torch.zeros((int(other), payload.shape[1]), dtype=torch.float64)
-        reqs = [dist.isend(torch.from_numpy(payload.astype(np.float64)), peer), dist.irecv(buf, peer)]
-        for r in reqs:
-            r.wait()
-        got[key] = buf.numpy()
-    return got
+        for key, buf in bufs.items():
+            a = buf.numpy()
+            got[key] = a[1:1 + int(a[0, 0]), :width]
+        return got
+
+    def allgather_far(self, payload, n_owned, step):
+        """The small all-gathered message for particles that cross more than one slab, and -- in its headers --
+        every rank's owned count and error bits of this step."""
+        width = payload.shape[1]
+        mine = self._message(payload, self.far_cap, width, n_owned, step, ERR_MIGRATION)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        self.tables[step] = np.stack([o.numpy()[0, :HDR] for o in out])
+        return [o.numpy()[1:1 + int(o.numpy()[0, 0]), :width] for o in out]
+
+    def check(self, step):
+        """What ws_step does first: the table of step - LAG; any rank's error bit fails every rank at this step."""
+        t = self.tables.get(step - self.LAG)
+        if t is not None and int(t[:, 1].max()) != 0:
+            raise OverflowError("step %d: rank(s) %s overran a message capacity at step %d"
+                                % (step, np.flatnonzero(t[:, 1]).tolist(), step - self.LAG))
 
 
 def main():
     out_path, steps = sys.argv[1], int(sys.argv[2])
+    halo_cap = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    proto = Protocol(rank, world, halo_cap=halo_cap, mig_cap=512, far_cap=64)
     params = ws.make_params(container_size=(8.0, 5.0, 5.0), gravity=(5.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(4096, 11, list(params.ext_min), list(params.ext_max))
     n = pos.shape[0]
@@ -68,13 +112,19 @@ def main():
     state["predicted_position"][:, :3] = pos[mine]
     lo, hi = cuts[rank], cuts[rank + 1]
     max_err = 0.0
+    failed_at = -1
     for step in range(steps):
+        try:
+            proto.check(step)
+        except OverflowError:
+            failed_at = step  # every rank raises here, at the same step, outside any collective
+            break
         gx = np.clip(xcell(params, state["predicted_position"], org), 0, nx - 1)
-        assert np.all((gx >= lo) & (gx < hi)), "ownership invariant"
+        assert np.all((gx >= lo) & (gx < hi)) or proto.err, "ownership invariant"
         # halo A: predicted positions (+ velocity, ids) of my first / last owned layer
         def pack(mask):
             return np.c_[ids[mask], state["predicted_position"][mask, :3], state["velocity"][mask, :3]].astype(np.float64)
-        ghosts = exchange(rank, world, pack(gx == lo), pack(gx == hi - 1))
+        ghosts = proto.exchange(pack(gx == lo), pack(gx == hi - 1), proto.halo_cap, len(state), step, ERR_HALO)
         g = [a for a in (ghosts["left"], ghosts["right"]) if a is not None and len(a)]
         g = np.concatenate(g) if g else np.zeros((0, 7))
         local = np.zeros(len(state) + len(g), O.PARTICLE_DTYPE)
@@ -89,11 +139,11 @@ def main():
         # halo B: the ghosts' densities come from their owners (a ghost's own neighbours are not all here)
         def packd(mask):
             return np.c_[ids[mask], orc.particles["density"][: len(state)][mask], orc.particles["pressure"][: len(state)][mask]].astype(np.float64)
-        dens = exchange(rank, world, packd(gx == lo), packd(gx == hi - 1))
+        dens = proto.exchange(packd(gx == lo), packd(gx == hi - 1), proto.halo_cap, len(state), step, ERR_HALO)
         d = [a for a in (dens["left"], dens["right"]) if a is not None and len(a)]
         if d:
             d = np.concatenate(d)
-            assert np.array_equal(d[:, 0].astype(np.int64), gid)  # same order as halo A
+            assert np.array_equal(d[:, 0].astype(np.int64), gid) or proto.err  # same order as halo A
             wrong = np.abs(orc.particles["density"][len(state):, 0] - d[:, 1]).max() if len(d) else 0.0
             orc.particles["density"][len(state):] = d[:, 1:3].astype(np.float32)
             orc.particles["pressure"][len(state):] = d[:, 3:5].astype(np.float32)
@@ -105,21 +155,25 @@ def main():
         state = orc.particles[: len(state)].copy()
         # migration: hand particles whose predicted x cell left [lo, hi) to the neighbour
         gx = np.clip(xcell(params, state["predicted_position"], org), 0, nx - 1)
-        assert np.all((gx >= lo - 1) & (gx <= hi)), "this small test only migrates to direct neighbours"
+        dest = np.searchsorted(cuts, gx, side="right") - 1  # the slab each particle belongs to now
         def packm(mask):
             return np.c_[ids[mask], state["position"][mask, :3], state["velocity"][mask, :3],
                          state["predicted_position"][mask, :3], state["density"][mask], state["acceleration"][mask, :3]].astype(np.float64)
-        arr = exchange(rank, world, packm(gx < lo), packm(gx >= hi))
-        keep = (gx >= lo) & (gx < hi)
+        # direct neighbours by send/recv; anything further through the small all-gathered message, tagged with its owner
+        arr = proto.exchange(packm(dest == rank - 1), packm(dest == rank + 1), proto.mig_cap, len(state), step, ERR_MIGRATION)
+        far = np.abs(dest - rank) > 1
+        far_all = proto.allgather_far(np.c_[packm(far), dest[far].astype(np.float64)], len(state), step)
+        keep = dest == rank
         state, ids = state[keep], ids[keep]
-        for a in (arr["left"], arr["right"]):
+        arrivals = [arr["left"], arr["right"]] + [a[a[:, -1] == rank, :-1] for q, a in enumerate(far_all) if q != rank]
+        for a in arrivals:
             if a is not None and len(a):
                 add = np.zeros(len(a), O.PARTICLE_DTYPE)
                 add["position"][:, :3] = a[:, 1:4]; add["velocity"][:, :3] = a[:, 4:7]
                 add["predicted_position"][:, :3] = a[:, 7:10]; add["density"] = a[:, 10:12]
                 add["acceleration"][:, :3] = a[:, 12:15]
                 state = np.concatenate([state, add]); ids = np.concatenate([ids, a[:, 0].astype(np.int64)])
-    np.savez(out_path % rank, ids=ids, state=state)
+    np.savez(out_path % rank, ids=ids, state=state, failed_at=failed_at)
     dist.barrier()
     dist.destroy_process_group()
 

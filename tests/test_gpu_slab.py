@@ -108,3 +108,24 @@ def test_native_rccl_transport_single_rank(ws):
     got[got_ids] = rec
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+@pytest.mark.parametrize("what", ["ghost_capacity", "capacity"])
+def test_capacity_overrun_fails_every_rank_alike_and_hangs_nobody(ws, what):
+    """A slab whose halo messages (ghost_capacity) or owned range (capacity) are too small: the kernels clamp and set
+    a sticky error bit, the bit travels to every rank with the next step's all-gather, and ws_step fails with
+    WS_ERR_OUT_OF_MEMORY on EVERY rank at the same step, before any collective of that step -- nobody is left
+    waiting inside one."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
+    world = 3
+    if what == "ghost_capacity":
+        kw = dict(ghost_capacity=64)           # a boundary layer holds ~1000 particles
+    else:
+        kw = dict(capacity=65536 // world + 256)  # the tilted gravity piles the fluid up in the last slab
+    errs = ws.slab.run_loopback(pos, params, world, 80, collect_errors=True, **kw)
+    assert sorted(errs) == list(range(world)), "every rank must fail: %r" % (errs,)
+    steps = {k for k, _ in errs.values()}
+    assert len(steps) == 1, "all ranks must fail at the same step: %r" % (errs,)
+    for k, e in errs.values():
+        assert e.status == 3 and "capacity" in str(e), e  # WS_ERR_OUT_OF_MEMORY

@@ -39,3 +39,17 @@ def test_two_rank_slab_model_matches_single_domain_oracle(oracle, ws, tmp_path):
         err = np.max(np.abs(got[f].astype(np.float64) - orc.particles[f].astype(np.float64)))
         scale = max(1.0, float(np.max(np.abs(orc.particles[f]))))
         assert err <= tol * scale, (f, err)
+
+
+def test_two_rank_slab_model_capacity_overrun_fails_on_every_rank_alike(tmp_path):
+    """A halo message too small for the boundary layer: the sender clamps and sets its sticky error bit, the bit
+    reaches every rank with the per-step all-gather, and BOTH ranks stop at the same step, two steps later,
+    outside any collective -- no rank is left waiting in one (csrc/ws_slab.inc, slab_consume_status)."""
+    pattern = str(tmp_path / "rank_%d.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="2", WSO_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "tests", "dist_cpu_slab_model.py"), pattern, "8", "16"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    failed = [int(np.load(pattern % r)["failed_at"]) for r in range(2)]
+    assert failed[0] == failed[1] and 2 <= failed[0] <= 3, failed

@@ -1164,13 +1164,18 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (k >= dyn[DY_N]) return;
     const uint32_t i = d.base + k;
+    // The cell the particle was binned into already says whether it stays: the local grid clamps x into
+    // [0, nxl - 1], so everything that left the owned layers 1 .. nxl-2 sits in a ghost layer.  4 bytes per
+    // particle; only the leavers read their records.
+    const uint32_t rowy = (uint32_t)(d.dim[1] * d.dim[2]), c = cid_cur[i];
+    if (c >= rowy && c < (uint32_t)(d.dim[0] - 1) * rowy) return;
     const float4 q = cur.pred[i];
     const float fx = floorf(q.x / d.h) - (float)d.org[0];
     const uint32_t gxg = (uint32_t)(int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
     uint32_t dest = 0;
     while (dest + 1 < world && gxg >= cuts[dest + 1]) dest++;
-    if (dest == me) return;
-    atomicSub(&count[cid_cur[i]], 1u);
+    if (dest == me) return;  // (cannot happen: kept as the definition of "leaves")
+    atomicSub(&count[c], 1u);
     cid_cur[i] = WS_DEAD;
     const uint32_t hs = atomicAdd(&dyn[DY_NHOLE], 1u);
     if (hs < hole_cap) hole[hs] = i;

@@ -370,9 +370,12 @@ class SlabWorker:
             pass
 
 
-def run_loopback(positions, params, world, steps, device=0, ieee_division=False):
+def run_loopback(positions, params, world, steps, device=0, ieee_division=False, capacity=0, ghost_capacity=0,
+                 collect_errors=False):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
-    particles of all slabs merged into original-id order.  Test helper for one-GPU boxes."""
+    particles of all slabs merged into original-id order.  Test helper for one-GPU boxes.
+    collect_errors: instead of raising, return {rank: (steps completed, exception)} for the slabs whose ws_step
+    failed (the capacity tests expect every rank to fail alike)."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     n = positions.shape[0]
     owner = assign(params, positions, world)
@@ -386,8 +389,17 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False)
         try:
             sel = np.flatnonzero(owner == r).astype(np.uint32)
             w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device,
-                           ieee_division=ieee_division)
-            w.run(steps)
+                           ieee_division=ieee_division, capacity=capacity, ghost_capacity=ghost_capacity)
+            if collect_errors:
+                for k in range(steps):
+                    try:
+                        w.run(1)
+                    except fluid.WsError as e:
+                        errors.append((r, (k, e)))
+                        w.close()
+                        return
+            else:
+                w.run(steps)
             rec, ids = w.read()
             out[ids] = rec
             np.add.at(seen, ids, 1)
@@ -402,6 +414,8 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False)
         t.start()
     for t in threads:
         t.join()
+    if collect_errors:
+        return dict(errors)
     if errors:
         raise RuntimeError("slab thread failed: %r" % (errors,))
     assert np.all(seen == 1), "every particle must be owned by exactly one slab"
