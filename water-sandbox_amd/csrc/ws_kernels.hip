@@ -842,6 +842,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     }
 }
 
+#ifndef NF_WORDSYNC_MAX
+#define NF_WORDSYNC_MAX 8  // mask words per particle up to which a wave takes the word-synchronous walk (2/3/5/8: within 1 %)
+#endif
 #ifndef NF_P
 #define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
 #endif
@@ -895,14 +898,61 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     if (!__ballot(total > 32u * ND_MASK_WORDS)) {
         const uint32_t *mrow = mask.words + (iv - d.base);
         const uint32_t nwords = (total + 31u) >> 5;
+        uint32_t run = 0, end_r = t_end[threadIdx.x], delta_r = t_delta[threadIdx.x];
+        const uint32_t self_s = i - t_delta[4 * NF_P + threadIdx.x];  // own candidate number (own cell = run 4)
+      if (!__ballot(nwords > (uint32_t)NF_WORDSYNC_MAX)) {
+        // A wave whose particles all have few candidates (the sparse state: 1-2 mask words each) walks its 64 masks
+        // WORD BY WORD, all lanes on the same word number: inside a word every lane takes its set bits one per
+        // trip (the neighbours in visit order).  The rare work -- next word, dropping the particle's own bit
+        // (simulation.wgsl:232 `particle_index == neighbour_index`) -- is done by all lanes at once, once per
+        // word; only the run switch stays per lane.  One neighbour's records are in flight while the previous
+        // one computes.  (C3, K5: -11 % at 21 candidates per particle, +24 % at 259 -- where a word's bit count
+        // differs too much between lanes -- hence the choice per wave.)
+        uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
+        bool pend = false;
+        float4 q_p = o, nvel_p = vel;
+        for (uint32_t w = 0; __ballot(w < nwords); w++) {
+            uint32_t bits = w < nwords ? wnext : 0u;
+            if (w == (self_s >> 5)) bits &= ~(1u << (self_s & 31u));
+            wnext = w + 1u < nwords ? mrow[(size_t)(w + 1u) * mask.stride] : 0u;
+            const uint32_t wbase = w << 5;
+            while (__ballot(bits != 0u)) {
+                const bool has = bits != 0u;
+                float4 q_n = q_p, nvel_n = nvel_p;
+                if (has) {
+                    const uint32_t sc = wbase + (uint32_t)__ffs((int)bits) - 1u;
+                    bits &= bits - 1u;
+                    while (sc >= end_r) {
+                        run++;
+                        end_r = t_end[run * NF_P + threadIdx.x];
+                        delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
+                    }
+                    const uint32_t j = sc + delta_r;
+                    q_n = srt.pred_near(j);
+                    nvel_n = srt.vel_near(j);
+                }
+                if (pend) {
+                    const float ex = q_p.x - o.x, ey = q_p.y - o.y, ez = q_p.z - o.z;
+                    force_pair<IEEE>(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q_p.w, nvel_p.w, nvel_p, vel, pressure,
+                                     near_pressure, acc, 1u);
+                }
+                pend = has;
+                q_p = q_n;
+                nvel_p = nvel_n;
+            }
+        }
+        if (pend) {
+            const float ex = q_p.x - o.x, ey = q_p.y - o.y, ez = q_p.z - o.z;
+            force_pair<IEEE>(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q_p.w, nvel_p.w, nvel_p, vel, pressure, near_pressure,
+                             acc, 1u);
+        }
+      } else {
         // Iterator over the set bits of the mask = the neighbours in visit order.  `avail` holds the pending
         // bits of the current word that belong to the current run, so the per-neighbour path is ffs + clear +
         // add; everything rare (next word, next run, dropping the particle's own bit -- simulation.wgsl:232
         // `particle_index == neighbour_index`) happens in advance().
-        uint32_t avail = 0, rest = 0, wbase = 0, widx = 0, run = 0;
+        uint32_t avail = 0, rest = 0, wbase = 0, widx = 0;
         uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
-        uint32_t end_r = t_end[threadIdx.x], delta_r = t_delta[threadIdx.x];
-        const uint32_t self_s = i - t_delta[4 * NF_P + threadIdx.x];  // own candidate number (own cell = run 4)
         auto advance = [&]() -> bool {
             while (rest == 0u) {
                 if (widx >= nwords) return false;
@@ -946,6 +996,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
             force_pair<IEEE>(d, ex, ey, ez, ex * ex + ey * ey + ez * ez, q.w, nvel.w, nvel, vel, pressure, near_pressure,
                              acc, 1u);
         }
+      }
     } else if (valid) {
         force_sweep_simple<false, IEEE>(d, start, srt, nullptr, i, o, vel, c, pressure, near_pressure, acc);
     }
