@@ -5,13 +5,14 @@
 // ONE contiguous particle run (9 runs per particle instead of 27 bucket walks).
 // No MFMA: the step is gather/scan/sort work bounded by HBM/L2/LDS and VALU.
 //
-// Arithmetic contract: every float expression below is written in the evaluation
-// order of the reference WGSL and this file is compiled with -ffp-contract=off, so
-// each operation is one IEEE binary32 operation, never a contracted multiply-add.  The
-// square root and the divisions of the pair terms come in two forms (template parameter
-// IEEE): correctly rounded, or the hardware's v_sqrt_f32 / v_rcp_f32 (see ws_sqrt /
-// WsDivisor).  What differs from the reference otherwise is only the ORDER in which
-// neighbours are visited (dense-grid order instead of hashed-bucket order).
+// Arithmetic contract: this file is compiled with -ffp-contract=off, so every operation below is one IEEE
+// binary32 operation, never a contracted multiply-add.  Hashing, cell assignment, the radius test, the density
+// terms and the integrator are written in the evaluation order of the reference WGSL.  The pair terms of the force
+// come in two forms (template parameter IEEE): WS_FLAG_IEEE_DIVISION = the reference's expression tree operation
+// for operation with correctly rounded sqrt / division; default = hardware v_sqrt_f32 / v_rcp_f32 (1 ULP) with
+// the scalar factors of a pair collected before they meet the direction vector (force_pair).  What differs from
+// the reference otherwise is only the ORDER in which neighbours are visited (dense-grid order instead of
+// hashed-bucket order).  Every parity test applies ONE tolerance to both forms.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -488,12 +489,12 @@ __device__ __forceinline__ uint32_t alias_mult(const WsDev &d, const uint8_t *__
 // per-pair arithmetic of K4 / K5, shared by every kernel variant.
 // ---------------------------------------------------------------------------------
 
-// sqrt and division of the pair terms.  IEEE = true: correctly rounded, the arithmetic of a CPU restatement (and
-// always of the reference-order validation mode).  IEEE = false (default of the production kernels): the
-// hardware's v_sqrt_f32 / v_rcp_f32 (1 ULP each), i.e. x / y evaluated as x * rcp(y) -- within the accuracy
-// the reference's shading language itself grants its GPU (WGSL: x / y 2.5 ULP, sqrt as 1 / inverseSqrt at
-// 2 ULP), written in the same operation order.  ~9 correctly rounded divisions and a square root cost ~110 of
-// the ~180 instructions of one force pair.
+// sqrt and division of the pair terms.  IEEE = true: correctly rounded, in the reference's operation order -- the
+// arithmetic of a CPU restatement (and always of the reference-order validation mode).  IEEE = false (default of
+// the production kernels): the hardware's v_sqrt_f32 / v_rcp_f32 (1 ULP each), x / y evaluated as x * rcp(y) --
+// within the accuracy the reference's shading language itself grants its GPU (WGSL: x / y 2.5 ULP, sqrt as
+// 1 / inverseSqrt at 2 ULP) -- and, in the force pair, the scalar factors collected first (force_pair).  ~9
+// correctly rounded divisions and a square root cost ~110 of the ~180 instructions of one IEEE force pair.
 template <bool IEEE>
 __device__ __forceinline__ float ws_sqrt(float x)
 {
@@ -534,31 +535,54 @@ __device__ __forceinline__ void force_pair(const WsDev &d, float ex, float ey, f
                                            ForceAcc &a, uint32_t mult)
 {
     const float dst = ws_sqrt<IEEE>(d2);
-    const WsDivisor<IEEE> by_dst(dst), by_rho(nrho_x), by_near_rho(nrho_y);
-    if (dst > 0.f) {
-        ex = by_dst(ex);
-        ey = by_dst(ey);
-        ez = by_dst(ez);
-    } else {
-        ex = 0.f;
-        ey = 1.f;
-        ez = 0.f;
-    }
     const float npress = d.pressure_scalar * (nrho_x - d.target_density);
     const float nnear = d.near_pressure_scalar * nrho_y;
     const float slope = sk_der(d, dst);
     const float shared = (pressure + npress) / 2.f;
     const float slope_near = sk_der_near(d, dst);
     const float shared_near = (near_pressure + nnear) / 2.f;
-    const float ax = by_rho(ex * shared * slope), ay = by_rho(ey * shared * slope), az = by_rho(ez * shared * slope);
-    const float bx = by_near_rho(ex * shared_near * slope_near), by = by_near_rho(ey * shared_near * slope_near),
-                bz = by_near_rho(ez * shared_near * slope_near);
-    const float visc = sk_visc(d, dst);
-    const float wx = (nvel.x - vel.x) * visc, wy = (nvel.y - vel.y) * visc, wz = (nvel.z - vel.z) * visc;
-    for (uint32_t r = 0; r < mult; r++) {
-        a.pfx += ax; a.pfy += ay; a.pfz += az;
-        a.pfx += bx; a.pfy += by; a.pfz += bz;
-        a.vfx += wx; a.vfy += wy; a.vfz += wz;
+    if constexpr (IEEE) {
+        // the reference's expression tree, operation for operation: ((dir * shared) * slope) / density per term
+        const WsDivisor<IEEE> by_dst(dst), by_rho(nrho_x), by_near_rho(nrho_y);
+        if (dst > 0.f) {
+            ex = by_dst(ex);
+            ey = by_dst(ey);
+            ez = by_dst(ez);
+        } else {
+            ex = 0.f;
+            ey = 1.f;
+            ez = 0.f;
+        }
+        const float ax = by_rho(ex * shared * slope), ay = by_rho(ey * shared * slope), az = by_rho(ez * shared * slope);
+        const float bx = by_near_rho(ex * shared_near * slope_near), by = by_near_rho(ey * shared_near * slope_near),
+                    bz = by_near_rho(ez * shared_near * slope_near);
+        const float visc = sk_visc(d, dst);
+        const float wx = (nvel.x - vel.x) * visc, wy = (nvel.y - vel.y) * visc, wz = (nvel.z - vel.z) * visc;
+        for (uint32_t r = 0; r < mult; r++) {
+            a.pfx += ax; a.pfy += ay; a.pfz += az;
+            a.pfx += bx; a.pfy += by; a.pfz += bz;
+            a.vfx += wx; a.vfy += wy; a.vfz += wz;
+        }
+    } else {
+        // Default arithmetic: the same pair terms with the scalar factors collected before they meet the direction
+        // vector -- dir * (shared * slope / rho + shared_near * slope_near / rho_near), divisions as reciprocal
+        // multiplies (hardware v_rcp_f32 / v_sqrt_f32, 1 ULP each) -- 17 of the ~65 operations of a pair fewer.  Each
+        // term differs from the reference's expression tree by a few ULP; the sums stay inside the tolerance every
+        // parity test applies to both arithmetics.  (Also measured: the neighbour's reciprocals prepared
+        // once per particle by K4 instead -- 9 operations fewer still, no faster: K5 is then no longer bound by them.)
+        const float sa = shared * slope * __builtin_amdgcn_rcpf(nrho_x);
+        const float sb = shared_near * slope_near * __builtin_amdgcn_rcpf(nrho_y);
+        const float f = sa + sb;
+        const float g = f * __builtin_amdgcn_rcpf(dst);
+        const bool apart = dst > 0.f;  // coincident particles: direction (0, 1, 0), simulation.wgsl:243-246
+        const float fx = apart ? ex * g : 0.f, fy = apart ? ey * g : f, fz = apart ? ez * g : 0.f;
+        const float hv = d.h * d.h - d2;
+        const float visc = hv * hv * hv * d.k_spikey;
+        const float wx = (nvel.x - vel.x) * visc, wy = (nvel.y - vel.y) * visc, wz = (nvel.z - vel.z) * visc;
+        for (uint32_t r = 0; r < mult; r++) {
+            a.pfx += fx; a.pfy += fy; a.pfz += fz;
+            a.vfx += wx; a.vfy += wy; a.vfz += wz;
+        }
     }
 }
 
