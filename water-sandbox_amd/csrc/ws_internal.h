@@ -43,10 +43,7 @@ struct WsDev {
 // words of the device block `dyn` of a slab handle
 enum {
     DY_N = 0,        // owned particles
-    DY_NHOLE,        // leavers of the step being migrated (all routes)
-    DY_LEAVE_L,      // ... by route: to the left neighbour, to the right neighbour, anywhere else
-    DY_LEAVE_R,
-    DY_LEAVE_FAR,
+    DY_NHOLE,        // leavers of the step being migrated (all routes; per route they are counted in the message headers)
     DY_GL,           // ghosts staged in front of / behind the owned range
     DY_GR,
     DY_ERR,          // sticky WS_DYN_ERR_* bits
@@ -270,7 +267,8 @@ void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint3
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
-                      uint32_t *count, uint32_t *status);
+                      uint32_t *count, uint32_t *status, uint32_t hole_cap, uint32_t *sendL, uint32_t *sendR,
+                      uint32_t *far_send, uint32_t step);
 void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
                    uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities, uint32_t step);
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,

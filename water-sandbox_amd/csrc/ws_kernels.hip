@@ -1254,15 +1254,19 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32
     cid_cur[i] = WS_DEAD;
     const uint32_t hs = atomicAdd(&dyn[DY_NHOLE], 1u);
     if (hs < hole_cap) hole[hs] = i;
+    // The record count of a message lives in its header word 0 and is counted there directly: final the moment
+    // this kernel is, no sealing pass.  (The receiver clamps it to the capacity; the other header words were
+    // written by the previous step's k_migrate_fill.)
     uint32_t *msg;
-    uint32_t slot, cap;
+    uint32_t cap;
     if (dest + 1u == me) {
-        msg = sendL; cap = mig_cap; slot = atomicAdd(&dyn[DY_LEAVE_L], 1u);
+        msg = sendL; cap = mig_cap;
     } else if (dest == me + 1u) {
-        msg = sendR; cap = mig_cap; slot = atomicAdd(&dyn[DY_LEAVE_R], 1u);
+        msg = sendR; cap = mig_cap;
     } else {
-        msg = far; cap = far_cap; slot = atomicAdd(&dyn[DY_LEAVE_FAR], 1u);
+        msg = far; cap = far_cap;
     }
+    const uint32_t slot = atomicAdd(&msg[0], 1u);
     if (slot >= cap) {  // the message is full: the particle is lost, the step is invalid -- say so
         atomicOr(&dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
         return;
@@ -1274,35 +1278,14 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32
     rec[3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
 }
 
-// ... and the headers of the three migration messages, once the counts are final
-__global__ void k_migrate_seal(uint32_t *__restrict__ dyn, uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
-                               uint32_t mig_cap, uint32_t *__restrict__ far, uint32_t far_cap, uint32_t hole_cap,
-                               uint32_t step)
-{
-    if (threadIdx.x != 0) return;
-    if (dyn[DY_NHOLE] > hole_cap) {
-        dyn[DY_ERR] |= WS_DYN_ERR_MIGRATION;
-        dyn[DY_NHOLE] = hole_cap;
-    }
-    const uint32_t err = dyn[DY_ERR], n = dyn[DY_N];
-    uint32_t *msgs[3] = {sendL, sendR, far};
-    const uint32_t cnt[3] = {min(dyn[DY_LEAVE_L], mig_cap), min(dyn[DY_LEAVE_R], mig_cap), min(dyn[DY_LEAVE_FAR], far_cap)};
-    for (int m = 0; m < 3; m++) {
-        msgs[m][0] = cnt[m];
-        msgs[m][1] = err;
-        msgs[m][2] = n;
-        msgs[m][3] = step;
-    }
-}
-
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
                       uint32_t *cid_cur, uint32_t *count, uint32_t *dyn, uint32_t *hole, uint32_t hole_cap, uint32_t *sendL,
                       uint32_t *sendR, uint32_t mig_cap, uint32_t *far, uint32_t far_cap, uint32_t step)
 {
+    (void)step;
     if (d.n)
         hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, cid_cur,
                            count, dyn, hole, hole_cap, sendL, sendR, mig_cap, far, far_cap);
-    hipLaunchKernelGGL(k_migrate_seal, dim3(1), dim3(64), 0, s, dyn, sendL, sendR, mig_cap, far, far_cap, hole_cap, step);
 }
 
 // Migration, part 2 (ONE workgroup; a step moves a few thousand particles at most): count the arrivals, fix the new
@@ -1318,7 +1301,10 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
                                                                  const uint32_t *__restrict__ far_all, uint32_t far_cap,
                                                                  uint32_t *__restrict__ tgt, uint32_t *__restrict__ src,
                                                                  WsSoA cur, uint32_t *__restrict__ cid_cur,
-                                                                 uint32_t *__restrict__ count, uint32_t *__restrict__ status)
+                                                                 uint32_t *__restrict__ count, uint32_t *__restrict__ status,
+                                                                 uint32_t hole_cap, uint32_t *__restrict__ sendL,
+                                                                 uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send,
+                                                                 uint32_t step)
 {
     __shared__ uint32_t s_far, s_ntgt, s_nsrc, s_nnew, s_nold, s_arr;
     const uint32_t tid = threadIdx.x;
@@ -1345,7 +1331,8 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
     }
     __syncthreads();
     const uint32_t nL = left ? min(recvL[0], mig_cap) : 0u, nR = right ? min(recvR[0], mig_cap) : 0u;
-    const uint32_t leave = dyn[DY_NHOLE];
+    const uint32_t leave = min(dyn[DY_NHOLE], hole_cap);
+    if (tid == 0 && dyn[DY_NHOLE] > hole_cap) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
     if (tid == 0) {
         const uint32_t n_old = dyn[DY_N];
         uint32_t arrivals = nL + nR + s_far;
@@ -1412,21 +1399,28 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
     if (tid == 0) {
         dyn[DY_N] = n_new;
         dyn[DY_NHOLE] = 0;
-        dyn[DY_LEAVE_L] = 0;
-        dyn[DY_LEAVE_R] = 0;
-        dyn[DY_LEAVE_FAR] = 0;
         dyn[DY_ARRIVED] += s_arr;
         dyn[DY_LEFT] += leave;
+        // the three outgoing migration messages of the NEXT step: counts back to zero (k_migrate_mark counts in
+        // place), and the status words every rank will read from the far message's header: sticky error bits, the
+        // owned count and the step they describe
+        sendL[0] = 0;
+        sendR[0] = 0;
+        far_send[0] = 0;
+        far_send[1] = dyn[DY_ERR];
+        far_send[2] = n_new;
+        far_send[3] = step + 1u;
     }
 }
 
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
-                      uint32_t *count, uint32_t *status)
+                      uint32_t *count, uint32_t *status, uint32_t hole_cap, uint32_t *sendL, uint32_t *sendR,
+                      uint32_t *far_send, uint32_t step)
 {
     hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
-                       mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status);
+                       mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status, hole_cap, sendL, sendR, far_send, step);
 }
 
 // Halo messages.  A: [header | cell-start slice of the boundary layer (rowy + 1 words, padded to 4) | its 32-byte
