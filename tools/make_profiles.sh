@@ -23,4 +23,12 @@ echo "traffic done"
 python3 bench.py > $out/bench_c3_cloud.json 2> $out/bench_c3_cloud.err
 python3 bench.py --dist lattice --no-cpu-baseline > $out/bench_c3_lattice.json 2> $out/bench_c3_lattice.err
 python3 bench.py --config c2 --no-cpu-baseline > $out/bench_c2_cloud.json 2> $out/bench_c2_cloud.err
+# the slab path with one rank through the native RCCL transport, same window as bench_c3_cloud (overhead of the slab step)
+WS_BENCH_FORCE_SLAB=1 python3 bench.py --no-cpu-baseline > $out/bench_c3_cloud_slab_one_rank.json 2> $out/bench_c3_cloud_slab_one_rank.err
+# copy the first window's traffic into place and print the driver line once more, now with roofline.traffic filled
+mkdir -p profiles/r02 && cp $out/traffic.json profiles/r02/traffic.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err
+tools/pmc.sh r02dense c3 cloud 400 3 abc > $out/pmc_dense.log 2>&1; python3 tools/pmc_report.py r02dense 3 > $out/pmc_c3_cloud_step400.txt 2>&1
+tools/pmc.sh r02sparse c3 cloud 10 3 abc > $out/pmc_sparse.log 2>&1; python3 tools/pmc_report.py r02sparse 3 > $out/pmc_c3_cloud_step10.txt 2>&1
+python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1
 echo done
