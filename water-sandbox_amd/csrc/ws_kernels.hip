@@ -772,6 +772,17 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nt)
 
 typedef float nd_f4 __attribute__((ext_vector_type(4)));
 typedef float nd_f4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive floats, 4-byte aligned
+typedef uint32_t nd_u4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Both ends of a run in ONE 16-byte load: the run of column cell `cc` is [start[cc - 1], start[cc + 2]), four
+// consecutive table entries (the texture addresser is the busiest unit of both neighbour kernels in the sparse state;
+// this halves their cell-table loads)
+__device__ __forceinline__ void run_bounds(const uint32_t *__restrict__ start, int cc, uint32_t &b, uint32_t &e)
+{
+    const nd_u4u v = *reinterpret_cast<const nd_u4u *>(start + (cc - 1));
+    b = v[0];
+    e = v[3];
+}
 
 // K4's phase 1 over one run on the planar arrays: 4 candidates per trip from three 16-B loads, the
 // squared distances as packed f32 vector arithmetic (same IEEE operations per candidate, same order).
@@ -847,8 +858,10 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
         const int cc = d.guard + c + (p - 1) * rowy;
         // unconditional (iv is always a real particle), so the six loads go out together
-        const uint32_t b0 = start[cc - rowz - 1], b1 = start[cc - 1], b2 = start[cc + rowz - 1];
-        uint32_t e0 = start[cc - rowz + 2], e1 = start[cc + 2], e2 = start[cc + rowz + 2];
+        uint32_t b0, b1, b2, e0, e1, e2;
+        run_bounds(start, cc - rowz, b0, e0);
+        run_bounds(start, cc, b1, e1);
+        run_bounds(start, cc + rowz, b2, e2);
         if (!valid) {
             e0 = b0;
             e1 = b1;
@@ -905,7 +918,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const int cc = d.guard + c + (p - 1) * rowy + (q - 1) * rowz;
-                b[q] = start[cc - 1];
+                b[q] = start[cc - 1];  // (one 16-B load for both, as in K4: -4 % sparse, +4.5 % dense here)
                 e[q] = start[cc + 2];
             }
 #pragma unroll
