@@ -202,7 +202,8 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  *   neighbour, plus one small all-gather for the rare particle that crosses several slabs in a step) -> sort own
  *   particles -> send the two boundary layers' records to the neighbours (halo A) -> K4 -> send their densities
  *   (halo B) -> K5+K6; with the halos on a second stream while the particles that need no ghosts compute.
- * ws_step NEVER WAITS FOR THE DEVICE on a slab handle either: every message has a fixed capacity known to both ends
+ * ws_step never waits for the step it enqueues on a slab handle either (the one thing it may wait for is the status
+ * table of the step enqueued two calls earlier -- a bounded run-ahead): every message has a fixed capacity known to both ends
  * (ghost_capacity and sizes derived from it) and carries its record count in a header; the owned count, the layer
  * ranges and the ghost counts stay on the device, kernels are launched over host-side upper bounds.  A capacity
  * overrun clamps, sets a sticky error bit that reaches every rank with the next step's all-gather, and makes ws_step

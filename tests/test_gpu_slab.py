@@ -129,3 +129,33 @@ def test_capacity_overrun_fails_every_rank_alike_and_hangs_nobody(ws, what):
     assert len(steps) == 1, "all ranks must fail at the same step: %r" % (errs,)
     for k, e in errs.values():
         assert e.status == 3 and "capacity" in str(e), e  # WS_ERR_OUT_OF_MEMORY
+
+
+def test_slab_step_only_enqueues(ws):
+    """`ws_step` on a slab handle never waits for the step it enqueues (counts stay on the device, messages have fixed
+    sizes); the only thing it may wait for is the status table of the step enqueued TWO calls earlier (a bounded
+    run-ahead: it is what lets every rank act on the same table).  So after a burst of calls the handle is still
+    busy -- at least the last two steps are still queued or running -- and the calls return before the work is done."""
+    import time
+
+    pos, params = ws.workloads.make_workload("c3", "cloud")
+    tr = ws.slab.NativeRcclTransport(ws.slab.NativeRcclTransport.unique_id(), 0, 1, 0)
+    ids = np.arange(pos.shape[0], dtype=np.uint32)
+    w = ws.slab.SlabWorker(pos, ids, pos.shape[0], params, 0, 1, tr)
+    w.run(3)
+    w.sync()
+    ready = ws.fluid.C.c_int(0)
+    assert w._L.ws_ready(w._h, ws.fluid.C.byref(ready)) == 0 and ready.value == 1
+    t0 = time.perf_counter()
+    w.run(12)
+    t_enqueued = time.perf_counter() - t0
+    assert w._L.ws_ready(w._h, ws.fluid.C.byref(ready)) == 0
+    busy = ready.value == 0
+    w.sync()
+    t_done = time.perf_counter() - t0
+    assert busy, "ws_ready reported 1 right after 12 slab steps of 4 194 304 particles were enqueued"
+    assert t_done - t_enqueued > 0.5e-3, "the last steps had already run when ws_step returned (%.2f / %.2f ms)" % (
+        t_enqueued * 1e3, t_done * 1e3)
+    assert w.num_owned() == pos.shape[0]
+    w.close()
+    tr.close()
