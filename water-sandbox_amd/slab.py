@@ -1,13 +1,14 @@
 """Multi-GPU slabs over the C ABI (include/wsfluid.h, "multi-GPU" section).
 
-Host-side plumbing only: the slab protocol itself (sort -> halo A -> K4 -> halo B -> K5+K6 ->
-migration) lives in the library (csrc/ws_slab.inc); this module supplies the transport callbacks
-it calls and a thin worker class.
+Host-side plumbing only: the slab protocol itself (migration -> sort -> halo A -> K4 -> halo B ->
+K5+K6, fixed-capacity messages with their counts in headers, no host round trip) lives in the
+library (csrc/ws_slab.inc); this module supplies the transports it calls and a thin worker class.
 
 Transports:
-  TorchDistTransport  one process per GPU, torch.distributed: RCCL ("nccl" backend) send/recv with
-                      the two x-neighbours + all_gather for migration, a gloo group for the few
-                      control words.  This is what bench.py uses.
+  NativeRcclTransport the library's own RCCL transport (csrc/ws_rccl.cpp): ncclSend / ncclRecv groups
+                      with the two x-neighbours + ncclAllGather, issued from C++ -- no Python in the
+                      step.  This is what bench.py uses.
+  TorchDistTransport  the same two callbacks on torch.distributed (RCCL or, in the tests, gloo).
   LoopbackHub         several slabs inside ONE process on ONE GPU, one host thread per slab,
                       device-to-device copies.  Lets the one-GPU test box exercise the whole slab
                       protocol (ghost indexing, migration, bit-exactness against one GPU).
@@ -22,7 +23,6 @@ from . import fluid
 
 SENDRECV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p)
-ALLGATHER_U32_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32))
 ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
@@ -43,7 +43,7 @@ def assign(params, positions, world_size):
 
 
 class _TransportBase:
-    """Wraps three Python methods as the C callback table; keeps the thunks alive."""
+    """Wraps two Python methods as the C callback table; keeps the thunks alive."""
 
     def __init__(self):
         self.error = None
@@ -62,13 +62,6 @@ class _TransportBase:
         m = 2 * nseg  # entry 2k + d: segment k, direction d (0 = left neighbour, 1 = right neighbour)
         return self._guard(self.sendrecv, [sp[i] for i in range(m)], [sb[i] for i in range(m)],
                            [rp[i] for i in range(m)], [rb[i] for i in range(m)], stream)
-
-    def _c_allgather_u32(self, ctx, inp, count, out):
-        def run():
-            res = self.allgather_u32([inp[i] for i in range(count)])
-            for i, v in enumerate(res):
-                out[i] = v
-        return self._guard(run)
 
     def _c_allgather_dev(self, ctx, sp, rp, nbytes, stream):
         return self._guard(self.allgather_dev, sp, rp, nbytes, stream)
@@ -136,12 +129,6 @@ class TorchDistTransport(_TransportBase):
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()  # stream-ordered on the current stream for the nccl backend
             self._fence()
-
-    def allgather_u32(self, values):
-        t = self.torch.tensor(values, dtype=self.torch.int64)
-        outs = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t, group=self.ctrl_group)
-        return [int(v) for o in outs for v in o.tolist()]
 
     def allgather_dev(self, sp, rp, nbytes, stream):
         src = self._tensor(sp, nbytes)
@@ -269,14 +256,6 @@ class _LoopbackTransport(_TransportBase):
             hub.copy(rp[i], psp[j], rb[i], stream)
         hub.done(stream)
         hub.barrier.wait()  # nobody reuses a send range before every reader is done
-
-    def allgather_u32(self, values):
-        hub = self.hub
-        hub.slots[self.rank] = list(values)
-        hub.barrier.wait()
-        out = [v for r in range(self.world) for v in hub.slots[r]]
-        hub.barrier.wait()
-        return out
 
     def allgather_dev(self, sp, rp, nbytes, stream):
         hub = self.hub
