@@ -250,7 +250,7 @@ hipEvent_t get_event(ws_handle *h)
         return e;
     }
     hipEvent_t e = nullptr;
-    hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;  // the bracket is then skipped, the step is not
     return e;
 }
 
@@ -264,13 +264,21 @@ struct Prof {
         p.kernel = k;
         p.a = get_event(h);
         p.b = get_event(h);
-        hipEventRecord(p.a, h->stream);
+        if (!p.a || !p.b || hipEventRecord(p.a, h->stream) != hipSuccess) {  // out of events: time nothing, run everything
+            if (p.a) h->pool.push_back(p.a);
+            if (p.b) h->pool.push_back(p.b);
+            on = false;
+        }
     }
     ~Prof()
     {
         if (!on) return;
-        hipEventRecord(p.b, h->stream);
-        h->pending.push_back(p);
+        if (hipEventRecord(p.b, h->stream) == hipSuccess) {
+            h->pending.push_back(p);
+        } else {
+            h->pool.push_back(p.a);
+            h->pool.push_back(p.b);
+        }
     }
 };
 

@@ -212,6 +212,7 @@ struct WsSlab {
     uint32_t n_known = 0;             // owned count as of step n_known_step
     uint64_t n_known_step = 0;
     uint32_t failed = 0;              // sticky WS_DYN_ERR_* bits seen on any rank
+    bool comm_failed = false;         // a transport call failed: the handle is dead
     // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute
     hipStream_t comm = nullptr, copy = nullptr;
     hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr, ev_filled = nullptr;
