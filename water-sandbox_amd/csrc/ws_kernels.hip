@@ -1236,6 +1236,7 @@ void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n)
 
 // message header: 4 words in front of every fixed-capacity message
 //   [0] records in the message   [1] sender's sticky error bits   [2] sender's owned count   [3] step stamp
+// ([1..3] matter in the all-gathered far message only: its headers are the per-step status table of all ranks)
 #define WS_HDR_WORDS 4u
 
 // Migration, part 1: find the particles whose predicted position left the slab; write their 64-byte records
