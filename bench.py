@@ -293,16 +293,17 @@ def main():
 
     if rank == 0:
         global_steps_per_s = args.steps / elapsed
-        # Unit of work = one step of a C3-sized (4 194 304-particle) share: the whole-job value is the global
-        # step rate times the number of such shares the job's configuration holds (1 at C3, 4 at C4, 16 at C5),
-        # so that value(N) / (N x value(1)) is the scaling efficiency.  The absolute step rate at the
-        # configuration's own size -- BASELINE.json's "steps/sec @ N particles" -- is global_steps_per_s.
-        shares = n_global / C3_PARTICLES if distributed else 1.0
+        # `value` = simulation steps/s of the configuration this N runs -- BASELINE.json's "steps/sec @ N particles"
+        # (C3 on one GPU, C4 on 4, C5 on 8): one step advances ALL particles of the job, so the global step rate IS
+        # the whole-job rate.  C4 on 4 GPUs holds as many particles per GPU as C3 on one (weak scaling: the step rate
+        # should stay level); `c3_equivalent_steps_per_s` = value x particles / 4 194 304 is the same throughput in
+        # steps of a C3-sized share, for whoever wants value(N) / (N x value(1)).
+        shares = n_global / C3_PARTICLES
         dist_name = ("uniform cloud seed 0x%X" % ws.workloads.cloud_seed(base_name)) if args.dist == "cloud" \
             else "cube_fluid lattice"
         out = {
             "metric": "simulation steps/sec @ N particles",
-            "value": shares * global_steps_per_s,
+            "value": global_steps_per_s,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -321,13 +322,14 @@ def main():
                 "particles_per_gpu": n_global // world,
                 "distribution": args.dist,
                 "container": [params.ext_min[i] for i in range(3)] + [params.ext_max[i] for i in range(3)],
-                "value_definition": "global simulation steps/s x (particles / 4 194 304): steps of a C3-sized share per "
-                                    "second, whole job; global_steps_per_s is the absolute step rate at this particle count",
+                "value_definition": "global simulation steps/s at this particle count (one step advances every particle "
+                                    "of the job); c3_equivalent_steps_per_s = value x particles / 4 194 304",
                 "arithmetic": "f32, every operation rounded as written (no FMA contraction); sqrt / division of the pair "
                               "terms: hardware v_sqrt_f32 / v_rcp_f32 (1 ULP) -- value_ieee: correctly rounded",
                 "readback_in_timed_region": False,
             },
             "global_steps_per_s": global_steps_per_s,
+            "c3_equivalent_steps_per_s": shares * global_steps_per_s,
             "particle_steps_per_s": global_steps_per_s * n_global,
             "algorithmic_GBps_step": B_ALG_STEP * n_global * global_steps_per_s / 1e9,
             "roofline": roof,
@@ -335,10 +337,10 @@ def main():
             "settled": settled,
         }
         if settled is not None:
-            settled["value"] = shares * settled["global_steps_per_s"]
+            settled["value"] = settled["global_steps_per_s"]
             settled["algorithmic_GBps_step"] = B_ALG_STEP * n_global * settled["global_steps_per_s"] / 1e9
         if ieee is not None:
-            out["value_ieee"] = shares * ieee["global_steps_per_s"]
+            out["value_ieee"] = ieee["global_steps_per_s"]
             out["ieee"] = ieee
         if transport is not None:
             out["config"]["transport"] = type(transport).__name__

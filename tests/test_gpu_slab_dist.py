@@ -53,7 +53,8 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
     assert line["unit"] == "steps/s" and line["value"] > 0 and line["config"]["particles"] == 2 * 4096
-    shares = line["config"]["particles"] / 4194304.0  # value counts steps of C3-sized shares
-    assert abs(line["value"] - shares * line["global_steps_per_s"]) < 1e-9 * line["value"]
+    assert line["value"] == line["global_steps_per_s"]  # steps/s of the configuration run: one step advances every particle
+    shares = line["config"]["particles"] / 4194304.0
+    assert abs(line["c3_equivalent_steps_per_s"] - shares * line["value"]) < 1e-9 * line["value"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert line["settled"] is not None and line["settled"]["steps"] == 100 and line["settled"]["warmup"] == 400
