@@ -10,6 +10,20 @@
 #include "wsfluid.h"
 
 // Everything a kernel needs besides array pointers; passed by value (kernarg / SGPRs).
+// Slab handles: where the force kernel's epilogue puts a particle whose new predicted position left the slab
+// (one copy in device memory, WsDev::mig points at it)
+struct WsMig {
+    const uint32_t *cuts;  // world + 1 global x-layer cuts
+    uint32_t world, me;
+    uint32_t *dyn;         // DY_* words
+    uint32_t *hole;        // indices the leavers vacate
+    uint32_t hole_cap;
+    uint32_t *sendL, *sendR;  // neighbour migration messages (header + mig_cap records of 64 B)
+    uint32_t mig_cap;
+    uint32_t *far;            // the all-gathered message for particles that cross several slabs
+    uint32_t far_cap;
+};
+
 struct WsDev {
     // FluidStaticProps, src/fluid_compute.rs:41-51
     float dt, damping, h, target_density, pressure_scalar, near_pressure_scalar, viscosity;
@@ -38,6 +52,7 @@ struct WsDev {
     uint32_t range_sel;            // WS_RANGE_*
     uint32_t has_left, has_right;  // x-neighbours present
     uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
+    const WsMig *mig;              // device copy; non-null = the force epilogue also does migration part 1
 };
 
 // words of the device block `dyn` of a slab handle
@@ -201,6 +216,7 @@ struct WsSlab {
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
     uint32_t *cuts_dev = nullptr;
     uint32_t *dyn = nullptr;          // WS_DYN_WORDS device words (DY_*)
+    WsMig *mig_dev = nullptr;         // device copy of the migration targets (WsDev::mig)
     uint32_t *hole = nullptr, *tgt = nullptr, *src = nullptr;  // migration index lists
     uint32_t *mig_sendL = nullptr, *mig_sendR = nullptr, *mig_recvL = nullptr, *mig_recvR = nullptr;
     uint32_t *far_send = nullptr, *far_all = nullptr;
@@ -262,9 +278,7 @@ inline void wsk_ref_load(hipStream_t, const ws_particle80 *, WsRef, uint32_t, bo
 inline void wsk_ref_store(hipStream_t, const WsDev &, WsRef, ws_particle80 *, uint32_t) {}
 #endif
 // slabs
-void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
-                      uint32_t *cid_cur, uint32_t *count, uint32_t *dyn, uint32_t *hole, uint32_t hole_cap, uint32_t *sendL,
-                      uint32_t *sendR, uint32_t mig_cap, uint32_t *far, uint32_t far_cap, uint32_t step);
+void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cur, uint32_t *count);
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,

@@ -139,6 +139,8 @@ void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur,
 // ---------------------------------------------------------------------------------
 // K1': cell binning (stand-alone form; the steady-state form is fused into k_force)
 // ---------------------------------------------------------------------------------
+#define WS_DEAD 0xFFFFFFFFu  // cell id of a slot whose particle has left the slab (slab handles)
+
 __global__ void __launch_bounds__(WS_BLOCK) k_bin(WsDev d, const float4 *__restrict__ pred,
                                                   uint32_t *__restrict__ cid, uint32_t *__restrict__ count,
                                                   uint32_t *__restrict__ rank)
@@ -357,15 +359,18 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ n_dev)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    const bool active = i < (n_dev ? *n_dev : n);  // slab handles: n is an upper bound, the count lives on the device
+    bool active = i < (n_dev ? *n_dev : n);  // slab handles: n is an upper bound, the count lives on the device
+    if (active && keys[i] == WS_DEAD) active = false;  // only after a migration overrun (the step is already flagged invalid)
     const uint32_t slot = wave_run_atomic_inc(cursor, active ? keys[i] : 0u, active);
     if (!active) return;
     slot_tmp[slot] = i;
     if (id_tmp) id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
 }
 
-// The same placement from ranks taken when the particles were binned (the force kernel's epilogue or k_bin):
-// slot = cell start + rank, no atomics.  Single-GPU handles; a slab's migration leaves holes in the ranks.
+// The same placement from ranks taken when the particles were binned (the force kernel's epilogue, k_bin, or
+// k_migrate_fill for a slab's arrivals): slot = cell start + rank, no atomics.  The ranks of a cell are gap-free
+// on a slab as well: a particle that leaves is never binned (force epilogue), one that arrives draws the next rank.
+// cid / rank / pos_with_id are indexed from the first owned particle; slots are absolute.
 __global__ void __launch_bounds__(WS_BLOCK) k_place(WsDev d, const uint32_t *__restrict__ cid,
                                                     const uint32_t *__restrict__ rank,
                                                     const float4 *__restrict__ pos_with_id,
@@ -373,7 +378,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_place(WsDev d, const uint32_t *__r
                                                     uint32_t *__restrict__ id_tmp)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= d.n) return;
+    if (i >= ws_n(d)) return;
+    if (cid[i] == WS_DEAD) return;  // only after a migration overrun (the step is already flagged invalid)
     const uint32_t slot = start[d.guard + cid[i]] + rank[i];
     slot_tmp[slot] = i;
     id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
@@ -407,6 +413,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     const uint32_t i = slot_tmp[s];
     const uint32_t id = id_tmp[s];
     const uint32_t c = cid_cur[i];
+    if (c == WS_DEAD) return;  // a stale slot after a migration overrun (the step is already flagged invalid)
     const uint32_t b = start[d.guard + c], e = start[d.guard + c + 1];
     uint32_t rank = 0;
     for (uint32_t t = b; t < e; t += 4) {  // four cell-mates per trip: their loads go out together
@@ -598,6 +605,48 @@ __device__ __forceinline__ void density_store(float density, float near_density,
     srt.vel(i).w = near_density;
 }
 
+// ---- slab handles: migration, part 1 -------------------------------------------------------------------------
+
+// message header: 4 words in front of every fixed-capacity message
+//   [0] records in the message   [1] sender's sticky error bits   [2] sender's owned count   [3] step stamp
+// ([1..3] matter in the all-gathered far message only: its headers are the per-step status table of all ranks)
+#define WS_HDR_WORDS 4u
+
+// The particle in slot i (not in the histogram, its cell id already WS_DEAD) left the slab: write its 64-byte record
+// {pos+id, vel, pred, destination} into the message for its route -- left neighbour, right neighbour, or the small
+// all-gathered "far" message for a particle that crosses more than one slab in a step -- and remember the hole it
+// leaves.  A message's record count lives in its header word 0 and is counted there directly (the receiver clamps
+// it to the capacity; the other header words were written by the previous k_migrate_fill).  Order is free
+// everywhere here: the sort is canonical.
+__device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint32_t i, float4 pos, float4 vel, float4 pred)
+{
+    const float fx = floorf(pred.x / d.h) - (float)d.org[0];
+    const uint32_t gxg = (uint32_t)(int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
+    uint32_t dest = 0;
+    while (dest + 1 < m.world && gxg >= m.cuts[dest + 1]) dest++;
+    const uint32_t hs = atomicAdd(&m.dyn[DY_NHOLE], 1u);
+    if (hs < m.hole_cap) m.hole[hs] = i;
+    uint32_t *msg;
+    uint32_t cap;
+    if (dest + 1u == m.me) {
+        msg = m.sendL; cap = m.mig_cap;
+    } else if (dest == m.me + 1u) {
+        msg = m.sendR; cap = m.mig_cap;
+    } else {
+        msg = m.far; cap = m.far_cap;
+    }
+    const uint32_t slot = atomicAdd(&msg[0], 1u);
+    if (slot >= cap || dest == m.me) {  // the message is full (or the grids disagree): the particle is lost, the step is invalid -- say so
+        atomicOr(&m.dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
+        return;
+    }
+    float4 *rec = reinterpret_cast<float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)slot;
+    rec[0] = pos;
+    rec[1] = vel;
+    rec[2] = pred;
+    rec[3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
+}
+
 // K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
 __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const ForceAcc &a, float rho_x, float4 vel,
                                                           uint32_t i, const float4 *__restrict__ pos, WsSoA out,
@@ -628,9 +677,17 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
 
     // next step's hash_particles (simulation.wgsl:130-141) on the dense grid
     const uint32_t nc = grid_cell(d, qx, qy, qz);
-    cid_out[i] = nc;
-    const uint32_t r = wave_run_atomic_inc(count, nc, true);  // one atomic per run of lanes that moved into the same cell
+    // On a slab handle a particle whose new cell lies in a ghost layer (the local grid clamps x into its layers) has
+    // left the slab: it is not binned, its record goes into a migration message instead (rare: a handful per step).
+    bool stays = true;
+    if (d.mig) {
+        const uint32_t rowy = (uint32_t)(d.dim[1] * d.dim[2]);
+        stays = nc >= rowy && nc < (uint32_t)(d.dim[0] - 1) * rowy;
+    }
+    cid_out[i] = stays ? nc : WS_DEAD;
+    const uint32_t r = wave_run_atomic_inc(count, nc, stays);  // one atomic per run of lanes that moved into the same cell
     if (out.rank) out.rank[i] = r;  // arrival rank inside the cell: the sort's tentative slot, without more atomics
+    if (!stays) migrate_out(d, *d.mig, i, make_float4(px, py, pz, p0.w), make_float4(vx, vy, vz, 0.f), make_float4(qx, qy, qz, 0.f));
 }
 
 // ---------------------------------------------------------------------------------
@@ -1232,74 +1289,25 @@ void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n)
 // numbers from there.  Every capacity overrun clamps (so nothing is written out of bounds) and sets a sticky bit
 // in dyn[DY_ERR], which travels to every rank with the next step's all-gather and fails ws_step on all of them.
 // ---------------------------------------------------------------------------------
-#define WS_DEAD 0xFFFFFFFFu
-
-// message header: 4 words in front of every fixed-capacity message
-//   [0] records in the message   [1] sender's sticky error bits   [2] sender's owned count   [3] step stamp
-// ([1..3] matter in the all-gathered far message only: its headers are the per-step status table of all ranks)
-#define WS_HDR_WORDS 4u
-
-// Migration, part 1: find the particles whose predicted position left the slab; write their 64-byte records
-// {pos+id, vel, pred, destination} into the message for their route (left neighbour, right neighbour, or the
-// small all-gathered "far" buffer for a particle that crosses more than one slab in a step), remember the holes
-// they leave, take them out of the histogram.  Order is free everywhere here: the sort is canonical.
-__global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, const uint32_t *__restrict__ cuts, uint32_t world,
-                                                           uint32_t me, WsSoA cur, uint32_t *__restrict__ cid_cur,
-                                                           uint32_t *__restrict__ count, uint32_t *__restrict__ dyn,
-                                                           uint32_t *__restrict__ hole, uint32_t hole_cap,
-                                                           uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
-                                                           uint32_t mig_cap, uint32_t *__restrict__ far, uint32_t far_cap)
+// Migration, part 1 for particles that no force kernel has seen yet (the first step after the upload; from then on
+// the force kernel's epilogue does this for the particles it moves): take the ones binned into a ghost layer out of
+// the histogram and hand them to migrate_out.  4 bytes per particle; only the leavers read their records.
+__global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, WsSoA cur, uint32_t *__restrict__ cid_cur,
+                                                           uint32_t *__restrict__ count)
 {
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (k >= dyn[DY_N]) return;
+    if (k >= d.dyn[DY_N]) return;
     const uint32_t i = d.base + k;
-    // The cell the particle was binned into already says whether it stays: the local grid clamps x into
-    // [0, nxl - 1], so everything that left the owned layers 1 .. nxl-2 sits in a ghost layer.  4 bytes per
-    // particle; only the leavers read their records.
     const uint32_t rowy = (uint32_t)(d.dim[1] * d.dim[2]), c = cid_cur[i];
     if (c >= rowy && c < (uint32_t)(d.dim[0] - 1) * rowy) return;
-    const float4 q = cur.pred[i];
-    const float fx = floorf(q.x / d.h) - (float)d.org[0];
-    const uint32_t gxg = (uint32_t)(int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
-    uint32_t dest = 0;
-    while (dest + 1 < world && gxg >= cuts[dest + 1]) dest++;
-    if (dest == me) return;  // (cannot happen: kept as the definition of "leaves")
     atomicSub(&count[c], 1u);
     cid_cur[i] = WS_DEAD;
-    const uint32_t hs = atomicAdd(&dyn[DY_NHOLE], 1u);
-    if (hs < hole_cap) hole[hs] = i;
-    // The record count of a message lives in its header word 0 and is counted there directly: final the moment
-    // this kernel is, no sealing pass.  (The receiver clamps it to the capacity; the other header words were
-    // written by the previous step's k_migrate_fill.)
-    uint32_t *msg;
-    uint32_t cap;
-    if (dest + 1u == me) {
-        msg = sendL; cap = mig_cap;
-    } else if (dest == me + 1u) {
-        msg = sendR; cap = mig_cap;
-    } else {
-        msg = far; cap = far_cap;
-    }
-    const uint32_t slot = atomicAdd(&msg[0], 1u);
-    if (slot >= cap) {  // the message is full: the particle is lost, the step is invalid -- say so
-        atomicOr(&dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
-        return;
-    }
-    float4 *rec = reinterpret_cast<float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)slot;
-    rec[0] = cur.pos[i];
-    rec[1] = cur.vel[i];
-    rec[2] = q;
-    rec[3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
+    migrate_out(d, *d.mig, i, cur.pos[i], cur.vel[i], cur.pred[i]);
 }
 
-void wsk_migrate_mark(hipStream_t s, const WsDev &d, const uint32_t *cuts, uint32_t world, uint32_t me, WsSoA cur,
-                      uint32_t *cid_cur, uint32_t *count, uint32_t *dyn, uint32_t *hole, uint32_t hole_cap, uint32_t *sendL,
-                      uint32_t *sendR, uint32_t mig_cap, uint32_t *far, uint32_t far_cap, uint32_t step)
+void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cur, uint32_t *count)
 {
-    (void)step;
-    if (d.n)
-        hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cuts, world, me, cur, cid_cur,
-                           count, dyn, hole, hole_cap, sendL, sendR, mig_cap, far, far_cap);
+    if (d.n) hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, cid_cur, count);
 }
 
 // Migration, part 2 (ONE workgroup; a step moves a few thousand particles at most): count the arrivals, fix the new
@@ -1401,12 +1409,13 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
             cur.pred[to] = q;
             const uint32_t c = grid_cell(d, q.x, q.y, q.z);
             cid_cur[to] = c;
-            atomicAdd(&count[c], 1u);
+            cur.rank[to] = atomicAdd(&count[c], 1u);  // the next rank of its cell (k_place)
         } else {
             cur.pos[to] = cur.pos[idx];
             cur.vel[to] = cur.vel[idx];
             cur.pred[to] = cur.pred[idx];
             cid_cur[to] = cid_cur[idx];
+            cur.rank[to] = cur.rank[idx];
         }
     }
     __syncthreads();
@@ -1415,7 +1424,7 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         dyn[DY_NHOLE] = 0;
         dyn[DY_ARRIVED] += s_arr;
         dyn[DY_LEFT] += leave;
-        // the three outgoing migration messages of the NEXT step: counts back to zero (k_migrate_mark counts in
+        // the three outgoing migration messages of the NEXT step: counts back to zero (migrate_out counts in
         // place), and the status words every rank will read from the far message's header: sticky error bits, the
         // owned count and the step they describe
         sendL[0] = 0;
