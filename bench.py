@@ -12,7 +12,9 @@ The workload is not stationary: a uniform cloud collapses 
 run: `value` = steps W..W+K of the trajectory (what the flags ask for), and `settled` = steps
 400..500 (the state the simulation lives in afterwards), each with its own roofline object.
 `value_ieee` is the first window again with WS_FLAG_IEEE_DIVISION (correctly rounded sqrt / division,
-the CPU restatement's arithmetic) instead of the hardware's 1-ULP forms.
+the CPU restatement's arithmetic) instead of the hardware's 1-ULP forms.  `with_readback` is the host
+application's frame pattern over the first window (positions read back every step, overlapped; PCIe
+inclusive, never `value`).
 
 For N > 1 the driver launches this under torch.distributed.run (one rank per GPU): N = 4 runs
 BASELINE.json's config 4 (C4, 16 777 216 particles) and N = 8 config 5 (C5, 67 108 864 particles) cut
@@ -63,6 +65,8 @@ def parse_args():
                          "particles per GPU at every N) instead of BASELINE.json's C4 / C5 geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settled", action="store_true", help="skip the settled-state window (steps 400..500)")
+    ap.add_argument("--no-readback", action="store_true",
+                    help="skip the frame-pattern leg (positions read back every step; PCIe inclusive)")
     ap.add_argument("--no-ieee", action="store_true", help="skip the WS_FLAG_IEEE_DIVISION repeat of the first window")
     ap.add_argument("--cpu-steps", type=int, default=12,
                     help="CPU-restatement steps timed for cpu_baseline (~10 s of CPU work at C3 on 16 threads)")
@@ -291,6 +295,32 @@ def main():
                 "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in i_prof.items() if v[1]}}
         w2.close()
 
+    # SURVEY 8(d)'s second number: the Bevy host's per-frame pattern (src/fluid_compute.rs:478: positions read back
+    # every frame) over the same window -- id-ordered positions, 12 B/particle, into a page-locked buffer, the copy
+    # of frame k overlapped with step k + 1 (ws_read_positions_begin / ws_step / ws_read_positions_end).  PCIe
+    # inclusive, so by definition never `value`.
+    with_readback = None
+    if not args.no_readback and not distributed:
+        import numpy as np
+
+        w3 = make_worker()
+        w3.run(args.warmup)
+        buf = np.empty((n_global, 3), np.float32)
+        w3.pin_host_buffer(buf)
+        w3.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            w3.read_positions_begin(buf)
+            w3.run(1)
+            w3.read_positions_end()
+        w3.sync()
+        r_elapsed = time.perf_counter() - t0
+        w3.unpin_host_buffer(buf)
+        w3.close()
+        with_readback = {"steps_per_s": args.steps / r_elapsed, "ms_per_frame": r_elapsed / args.steps * 1e3,
+                         "pattern": "per frame: ws_read_positions_begin (id order, 12 B/particle, pinned host buffer), "
+                                    "ws_step, ws_read_positions_end; same window as `value`"}
+
     if rank == 0:
         global_steps_per_s = args.steps / elapsed
         # `value` = simulation steps/s of the configuration this N runs -- BASELINE.json's "steps/sec @ N particles"
@@ -342,6 +372,8 @@ def main():
         if ieee is not None:
             out["value_ieee"] = ieee["global_steps_per_s"]
             out["ieee"] = ieee
+        if with_readback is not None:
+            out["with_readback"] = with_readback
         if transport is not None:
             out["config"]["transport"] = type(transport).__name__
         if grid is not None:

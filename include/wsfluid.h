@@ -250,6 +250,11 @@ ws_status ws_slab_create(const ws_params *params, const float *pos_xyz, const ui
 /* The particles this slab owns now (count varies with migration): up to cap records and their global
  * ids, in no particular order; *n_out = number owned.  Waits for enqueued steps. */
 ws_status ws_slab_read_particles(ws_handle *h, ws_particle80 *out, uint32_t *out_ids, uint32_t cap, uint32_t *n_out);
+/* Migration counters of this slab since it was created, as of the last migration that has run (waits for enqueued
+ * steps): out[0] = particles owned now, out[1] = particles that left, out[2] = particles that arrived, out[3] = of
+ * those that left, the ones that crossed more than one slab in a step (the all-gathered route).  The reference is a
+ * single-GPU program and has no counterpart; diagnostics for the host and for the tests. */
+ws_status ws_slab_counters(ws_handle *h, uint64_t out[4]);
 
 /* ---- reference-layout views of the sort (diagnostic; computed on demand by HIP
  *      kernels, never inside ws_step) ---------------------------------------------

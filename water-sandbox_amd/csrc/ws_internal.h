@@ -64,6 +64,7 @@ enum {
     DY_ERR,          // sticky WS_DYN_ERR_* bits
     DY_LEFT,         // cumulative: particles that left / arrived
     DY_ARRIVED,
+    DY_FAR,          // cumulative: leavers that took the all-gathered route (crossed more than one slab in a step)
     WS_DYN_WORDS = 16
 };
 enum {

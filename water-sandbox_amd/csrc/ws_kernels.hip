@@ -634,6 +634,7 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
         msg = m.sendR; cap = m.mig_cap;
     } else {
         msg = m.far; cap = m.far_cap;
+        atomicAdd(&m.dyn[DY_FAR], 1u);
     }
     const uint32_t slot = atomicAdd(&msg[0], 1u);
     if (slot >= cap || dest == m.me) {  // the message is full (or the grids disagree): the particle is lost, the step is invalid -- say so

@@ -278,6 +278,7 @@ class SlabWorker:
         L.ws_slab_create.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(fluid.WsDeviceCfg), C.POINTER(WsTransport), C.POINTER(C.c_void_p)]
         L.ws_slab_read_particles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.ws_slab_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         self.transport = transport  # keep the callback thunks alive
         self.rank, self.world, self.n_global = rank, world, n_global
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -313,6 +314,12 @@ class SlabWorker:
         """Particles this slab owns after the steps enqueued so far (the count lives on the device: waits for them)."""
         self.sync()
         return int(self._L.ws_num_particles(self._h))
+
+    def counters(self):
+        """Migration counters since creation (ws_slab_counters): owned now, left, arrived, left by the far route."""
+        out = (C.c_uint64 * 4)()
+        self._check(self._L.ws_slab_counters(self._h, out))
+        return {"owned": int(out[0]), "left": int(out[1]), "arrived": int(out[2]), "far": int(out[3])}
 
     def read(self):
         """(records[n_owned], ids[n_owned]) of the particles this slab owns now."""
@@ -350,11 +357,12 @@ class SlabWorker:
 
 
 def run_loopback(positions, params, world, steps, device=0, ieee_division=False, capacity=0, ghost_capacity=0,
-                 collect_errors=False):
+                 collect_errors=False, counters=None):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
     particles of all slabs merged into original-id order.  Test helper for one-GPU boxes.
     collect_errors: instead of raising, return {rank: (steps completed, exception)} for the slabs whose ws_step
-    failed (the capacity tests expect every rank to fail alike)."""
+    failed (the capacity tests expect every rank to fail alike).
+    counters: a dict that receives {rank: SlabWorker.counters()} taken after the last step."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     n = positions.shape[0]
     owner = assign(params, positions, world)
@@ -383,6 +391,8 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
             out[ids] = rec
             np.add.at(seen, ids, 1)
             owned_counts[r] = len(ids)
+            if counters is not None:
+                counters[r] = w.counters()
             w.close()
         except Exception as e:  # pragma: no cover - surfaced by the caller
             errors.append((r, e))
