@@ -312,7 +312,7 @@ void enqueue_step(ws_handle *h)
     }
     {
         Prof p(h, WS_K_REORDER);
-        wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz);
+        wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
     }
     {
         Prof p(h, WS_K_DENSITY);
@@ -323,6 +323,7 @@ void enqueue_step(ws_handle *h)
         wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
                   h->variant, h->ieee, h->mask);
     }
+    h->pred_stale = true;  // the epilogue stores position and velocity only (k_reorder)
 }
 
 // reference-order mode: (re)load the by-id arrays from 80-byte records
@@ -348,9 +349,18 @@ ws_status ref_upload_positions(ws_handle *h, const float *pos_xyz)
     return ref_load(h, rec.data(), true);
 }
 
-// Put freshly uploaded `cur` into the "binned" state every ws_step starts from.
+// cur.pred is not maintained by the step loop (k_reorder recomputes it): bring it up to date for a reader off the loop
+void refresh_pred(ws_handle *h, const WsDev &d)
+{
+    if (!h->pred_stale) return;
+    wsk_refresh_pred(h->stream, d, h->cur);
+    h->pred_stale = false;
+}
+
+// Put `cur` (freshly uploaded, or the current state after a re-grid) into the "binned" state every ws_step starts from.
 ws_status bin_current(ws_handle *h)
 {
+    refresh_pred(h, h->dev);
     HIP_TRY(h, hipMemsetAsync(h->count, 0, (size_t)h->dev.ncells * 4, h->stream));
     {
         Prof pr(h, WS_K_BIN);
@@ -368,6 +378,7 @@ ws_status upload_positions(ws_handle *h, const float *pos_xyz)
     HIP_TRY(h, hipMemcpyAsync(h->stage, pos_xyz, bytes, hipMemcpyHostToDevice, h->stream));
     wsk_upload_positions(h->stream, (const float *)h->stage, h->cur, h->n);
     HIP_TRY(h, hipGetLastError());
+    h->pred_stale = false;
     st = bin_current(h);
     if (st) return st;
     // the caller's buffer must not be referenced after return
@@ -839,6 +850,7 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return WS_OK;
     }
+    refresh_pred(h, h->dev);
     wsk_gather_particles(h->stream, h->dev, h->cur, h->srt, h->accel, h->steps > 0, (ws_particle80 *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -868,6 +880,7 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
     HIP_TRY(h, hipMemcpyAsync(h->stage, in, bytes, hipMemcpyHostToDevice, h->stream));
     wsk_upload_particles(h->stream, (const ws_particle80 *)h->stage, h->cur, h->n);
     HIP_TRY(h, hipGetLastError());
+    h->pred_stale = false;  // the caller's predicted positions, as they are
     st = bin_current(h);
     if (st) return st;
     HIP_TRY(h, hipStreamSynchronize(h->stream));

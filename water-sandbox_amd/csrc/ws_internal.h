@@ -197,6 +197,7 @@ struct ws_handle {
     WsRef ref;
 
     // slab (multi-GPU) state; slab == nullptr on a single-GPU handle
+    bool pred_stale = false;  // cur.pred is behind cur.pos / cur.vel (the step loop does not store it: k_reorder)
     struct WsSlab *slab = nullptr;
     bool own_stream = true;
 
@@ -250,7 +251,9 @@ uint32_t wsk_scan_state_words(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
                  uint32_t *id_tmp, uint32_t n, const uint32_t *n_dev);
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz);
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz,
+                 bool recompute_pred);
+void wsk_refresh_pred(hipStream_t s, const WsDev &d, WsSoA cur);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz);
 uint32_t wsk_mask_words(void);

@@ -401,6 +401,12 @@ void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id,
 
 // `cur` and cid_cur are indexed from the first owned particle (the caller passes offset pointers);
 // srt / cid_srt / slot_tmp / id_tmp are indexed absolutely.
+// RECOMPUTE_PRED: the force kernel's epilogue does not store the predicted positions it bins by -- they are
+// pos + vel * look-ahead of the values it does store, and the same two operations here give the same bits
+// (simulation.wgsl:307).  After an upload (ws_create, ws_reset, ws_write_particles, a slab's first step) the stored
+// `cur.pred` is used instead: the caller's predicted positions are taken as they are.
+#define WS_LOOKAHEAD 0.02f  // 1. / 50., simulation.wgsl:3
+template <bool RECOMPUTE_PRED>
 __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *__restrict__ slot_tmp,
                                                       const uint32_t *__restrict__ id_tmp,
                                                       const uint32_t *__restrict__ cid_cur,
@@ -423,9 +429,14 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
                 ((t + 3u < e && a3 < id) ? 1u : 0u);
     }
     const uint32_t dst = b + rank;
-    const float4 q = cur.pred[i];
-    srt.pos[dst] = cur.pos[i];
-    srt.vel(dst) = cur.vel[i];
+    const float4 p = cur.pos[i], v = cur.vel[i];
+    float4 q;
+    if constexpr (RECOMPUTE_PRED)
+        q = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
+    else
+        q = cur.pred[i];
+    srt.pos[dst] = p;
+    srt.vel(dst) = v;
     srt.pred(dst) = q;
     // K4's radius tests read the predicted positions as three planar arrays: one 16-B load there
     // fetches x (or y, z) of FOUR consecutive candidates
@@ -436,10 +447,31 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
 }
 
 void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz)
+                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz,
+                 bool recompute_pred)
 {
-    hipLaunchKernelGGL(k_reorder, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur, start,
-                       cur, srt, cid_srt, sxyz);
+    if (recompute_pred)
+        hipLaunchKernelGGL(k_reorder<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur,
+                           start, cur, srt, cid_srt, sxyz);
+    else
+        hipLaunchKernelGGL(k_reorder<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur,
+                           start, cur, srt, cid_srt, sxyz);
+}
+
+// cur.pred of the owned particles from their stored position and velocity (see k_reorder): for the paths off the
+// step loop that read it -- the 80-byte record views, re-binning after a parameter change
+__global__ void __launch_bounds__(WS_BLOCK) k_refresh_pred(WsDev d, WsSoA cur)
+{
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (k >= ws_n(d)) return;
+    const uint32_t i = d.base + k;
+    const float4 p = cur.pos[i], v = cur.vel[i];
+    cur.pred[i] = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
+}
+
+void wsk_refresh_pred(hipStream_t s, const WsDev &d, WsSoA cur)
+{
+    if (d.n) hipLaunchKernelGGL(k_refresh_pred, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur);
 }
 
 // ---------------------------------------------------------------------------------
@@ -670,11 +702,10 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
     if (px < d.ext_min[0]) { vx *= nd; px = d.ext_min[0]; } else if (px > d.ext_max[0]) { vx *= nd; px = d.ext_max[0]; }
     if (py < d.ext_min[1]) { vy *= nd; py = d.ext_min[1]; } else if (py > d.ext_max[1]) { vy *= nd; py = d.ext_max[1]; }
     if (pz < d.ext_min[2]) { vz *= nd; pz = d.ext_min[2]; } else if (pz > d.ext_max[2]) { vz *= nd; pz = d.ext_max[2]; }
-    const float LOOKAHEAD = 0.02f;  // 1. / 50., simulation.wgsl:3
-    const float qx = px + vx * LOOKAHEAD, qy = py + vy * LOOKAHEAD, qz = pz + vz * LOOKAHEAD;
+    const float qx = px + vx * WS_LOOKAHEAD, qy = py + vy * WS_LOOKAHEAD, qz = pz + vz * WS_LOOKAHEAD;
     out.pos[i] = make_float4(px, py, pz, p0.w);
     out.vel[i] = make_float4(vx, vy, vz, 0.f);
-    out.pred[i] = make_float4(qx, qy, qz, 0.f);
+    // (the predicted position is not stored: k_reorder recomputes it from the two records above, same bits)
 
     // next step's hash_particles (simulation.wgsl:130-141) on the dense grid
     const uint32_t nc = grid_cell(d, qx, qy, qz);
