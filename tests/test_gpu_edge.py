@@ -101,6 +101,35 @@ def test_set_params_gravity_and_radius_change(oracle, ws):
     w.close()
 
 
+def test_record_view_reports_the_last_steps_acceleration_whatever_happens_after_it(ws):
+    """The step does not store accelerations; ws_read_particles computes them on demand from the state the last step
+    left behind.  They must be the ones that step USED: reading twice gives the same bits, and a parameter change
+    (viscosity, pressure; a new radius that throws the grid away) between the step and the read does not leak in."""
+    pos = ws.workloads.uniform_cloud(20000, 3, [-2.9, -1.9, -1.9], [2.9, 1.9, 1.9])
+    params = ws.make_params(container_size=(6.0, 4.0, 4.0))
+
+    def after(change):
+        w = ws.FluidWorker(pos, params)
+        w.run(5)
+        if change is not None:
+            w.set_params(change)
+        out = w.read_vec("particles")
+        again = w.read_vec("particles")
+        w.close()
+        for f in out.dtype.names:
+            assert np.array_equal(out[f].view(np.uint32), again[f].view(np.uint32)), f
+        return out
+
+    want = after(None)
+    assert np.abs(want["acceleration"][:, :3]).max() > 0
+    for change in (ws.make_params(container_size=(6.0, 4.0, 4.0), viscosity_strength=0.4, pressure_scalar=50.0),
+                   ws.make_params(container_size=(6.0, 4.0, 4.0), smoothing_radius=0.35),
+                   ws.make_params(container_size=(6.0, 4.0, 4.0), gravity=(1.0, 2.0, 3.0, 0.0))):
+        got = after(change)
+        for f in ("acceleration", "position", "velocity", "predicted_position"):
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
 def test_reset_restores_initial_state_and_identity_views(ws):
     pos = ws.cube_fluid(8, 8, 8)
     w = ws.FluidWorker(pos, ws.make_params(container_size=(4.0, 4.0, 4.0)))

@@ -57,6 +57,31 @@ def test_particles_that_cross_several_slabs_in_one_step_take_the_far_route(ws):
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
+def test_parameter_change_on_slab_handles_matches_the_single_handle(ws):
+    """ws_set_params on slab handles in the middle of a run (gravity turned, viscosity doubled -- what the reference's
+    update() pushes every frame): the slabs keep their layer ranges, neighbours and migration targets, and the merged
+    result equals the single handle given the same change at the same step."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    later = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(-8.0, -9.8, 2.0, 0.0), viscosity_strength=0.2)
+    pos = ws.workloads.uniform_cloud(32768, 21, list(params.ext_min), list(params.ext_max))
+    w = ws.FluidWorker(pos, params)
+    w.run(12)
+    w.set_params(later)
+    w.run(18)
+    want = w.read_vec("particles")
+    w.close()
+    got, owned = ws.slab.run_loopback(pos, params, 3, 30, change_params=(12, later))
+    assert sum(owned) == pos.shape[0]
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+    # the radius is fixed on a slab
+    tr = ws.slab.LoopbackHub(1).transport(0)
+    s = ws.slab.SlabWorker(pos, np.arange(pos.shape[0], dtype=np.uint32), pos.shape[0], params, 0, 1, tr)
+    with pytest.raises(ws.fluid.WsError):
+        s.set_params(ws.make_params(container_size=(16.0, 9.0, 9.0), smoothing_radius=0.35))
+    s.close()
+
+
 def test_slab_assign_matches_cell_cuts(ws):
     params = ws.make_params(container_size=(16.0, 9.0, 9.0))
     pos = ws.workloads.uniform_cloud(20000, 5, list(params.ext_min), list(params.ext_max))

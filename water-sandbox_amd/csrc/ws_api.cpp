@@ -321,9 +321,10 @@ void enqueue_step(ws_handle *h)
     {
         Prof p(h, WS_K_FORCE);
         wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->ieee, h->mask);
+                  h->variant, h->ieee, h->mask, false);
     }
-    h->pred_stale = true;  // the epilogue stores position and velocity only (k_reorder)
+    h->pred_stale = true;   // the epilogue stores position and velocity only (k_reorder)
+    h->accel_stale = true;  // ... and no accelerations (refresh_accel)
 }
 
 // reference-order mode: (re)load the by-id arrays from 80-byte records
@@ -357,6 +358,26 @@ void refresh_pred(ws_handle *h, const WsDev &d)
     h->pred_stale = false;
 }
 
+// The accelerations of the last step, for the 80-byte record views: the force kernel once more over the sorted state
+// that step left behind (cell table, sorted records with densities, accept masks: all intact until the next step
+// starts), storing nothing but accel[].  Not profiled: it is not part of a step.
+ws_status refresh_accel(ws_handle *h)
+{
+    if (!h->accel_stale || h->refmode) return WS_OK;
+    WsDev d = h->dev;
+    if (h->slab) {
+        d.dyn = h->slab->dyn;
+        d.range_sel = 0;
+        d.n = h->slab->cap;  // upper bound; the kernel reads the owned count from the device
+    }
+    if (d.n)
+        wsk_force(h->stream, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
+                  h->variant, h->ieee, h->mask, true);
+    HIP_TRY(h, hipGetLastError());
+    h->accel_stale = false;
+    return WS_OK;
+}
+
 // Put `cur` (freshly uploaded, or the current state after a re-grid) into the "binned" state every ws_step starts from.
 ws_status bin_current(ws_handle *h)
 {
@@ -379,6 +400,7 @@ ws_status upload_positions(ws_handle *h, const float *pos_xyz)
     wsk_upload_positions(h->stream, (const float *)h->stage, h->cur, h->n);
     HIP_TRY(h, hipGetLastError());
     h->pred_stale = false;
+    h->accel_stale = false;  // no step yet: the views report zero acceleration
     st = bin_current(h);
     if (st) return st;
     // the caller's buffer must not be referenced after return
@@ -707,14 +729,28 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
                  memcmp(nd.org, od.org, sizeof nd.org);
         nd.dim[0] = od.dim[0]; nd.gdim_x = od.gdim_x; nd.xoff = od.xoff; nd.ncells = od.ncells; nd.guard = od.guard;
         nd.base = od.base; nd.n = od.n; nd.hash_n = od.hash_n;
+        nd.has_left = od.has_left; nd.has_right = od.has_right; nd.mig = od.mig;
+        memcpy(nd.lidx, od.lidx, sizeof nd.lidx);
+    }
+    if (h->refmode) regrid = false;  // no cell grid in reference-order mode
+    if (h->slab && regrid)
+        return fail(h, WS_ERR_UNSUPPORTED, "a slab handle cannot re-grid (smoothing radius / container are fixed)");
+    // The last step's accelerations are computed on demand from the state and the parameters that step used: if a
+    // parameter they depend on changes (or the grid goes away), compute them now.  (A host that pushes unchanged
+    // parameters every frame, as the reference's update() does, pays nothing.)
+    const bool accel_params_changed =
+        nd.h != od.h || nd.target_density != od.target_density || nd.pressure_scalar != od.pressure_scalar ||
+        nd.near_pressure_scalar != od.near_pressure_scalar || nd.viscosity != od.viscosity || nd.k_pow2_der != od.k_pow2_der ||
+        nd.k_pow3_der != od.k_pow3_der || nd.k_spikey != od.k_spikey || nd.d2_accept != od.d2_accept;
+    if (regrid || accel_params_changed) {
+        st = refresh_accel(h);
+        if (st) return st;
     }
     h->params = *params;
-    if (h->refmode) regrid = false;  // no cell grid in reference-order mode
     if (!regrid) {
         h->dev = nd;  // by-value kernel argument: picked up by the next ws_step
         return WS_OK;
     }
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "a slab handle cannot re-grid (smoothing radius / container are fixed)");
     // cell size or container changed: rebuild the grid tables and re-bin the current state
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->dev = nd;
@@ -851,6 +887,8 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
         return WS_OK;
     }
     refresh_pred(h, h->dev);
+    st = refresh_accel(h);
+    if (st) return st;
     wsk_gather_particles(h->stream, h->dev, h->cur, h->srt, h->accel, h->steps > 0, (ws_particle80 *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -881,6 +919,7 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
     wsk_upload_particles(h->stream, (const ws_particle80 *)h->stage, h->cur, h->n);
     HIP_TRY(h, hipGetLastError());
     h->pred_stale = false;  // the caller's predicted positions, as they are
+    h->accel_stale = false;
     st = bin_current(h);
     if (st) return st;
     HIP_TRY(h, hipStreamSynchronize(h->stream));

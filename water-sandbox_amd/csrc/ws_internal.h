@@ -197,6 +197,7 @@ struct ws_handle {
     WsRef ref;
 
     // slab (multi-GPU) state; slab == nullptr on a single-GPU handle
+    bool accel_stale = false;  // accel[] is behind the last step (computed on demand: refresh_accel)
     bool pred_stale = false;  // cur.pred is behind cur.pos / cur.vel (the step loop does not store it: k_reorder)
     struct WsSlab *slab = nullptr;
     bool own_stream = true;
@@ -259,7 +260,7 @@ void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uin
 uint32_t wsk_mask_words(void);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
-               WsMask mask);
+               WsMask mask, bool accel_only);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
 void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,

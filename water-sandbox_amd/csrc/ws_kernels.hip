@@ -681,6 +681,10 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
 }
 
 // K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
+// The acceleration itself (the reference's `acceleration` field, read by nothing but the 80-byte record view) is not
+// stored by the step: ACCEL_ONLY = the same kernel run again over the same sorted state, on demand, storing just
+// that (ws_read_particles; same code, same inputs, same visit order: the bits the step used).
+template <bool ACCEL_ONLY>
 __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const ForceAcc &a, float rho_x, float4 vel,
                                                           uint32_t i, const float4 *__restrict__ pos, WsSoA out,
                                                           float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
@@ -689,7 +693,10 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
     const float accx = a.pfx / rho_x + a.vfx * d.viscosity;
     const float accy = a.pfy / rho_x + a.vfy * d.viscosity;
     const float accz = a.pfz / rho_x + a.vfz * d.viscosity;
-    accel[i] = make_float4(accx, accy, accz, 0.f);
+    if constexpr (ACCEL_ONLY) {
+        accel[i] = make_float4(accx, accy, accz, 0.f);
+        return;
+    }
 
     const float4 p0 = pos[i];
     float vx = vel.x + (d.grav[0] + accx) * d.dt;
@@ -787,7 +794,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint
     density_store(density, near_density, i, srt);
 }
 
-template <bool ALIAS, bool IEEE>
+template <bool ALIAS, bool IEEE, bool ACCEL_ONLY>
 __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32_t *__restrict__ start,
                                                            const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                            float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
@@ -803,7 +810,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
     const float near_pressure = d.near_pressure_scalar * vel.w;
     ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     force_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, i, o, vel, (int)cid_srt[i], pressure, near_pressure, acc);
-    force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
+    force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
 // ---------------------------------------------------------------------------------
@@ -975,7 +982,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
 #endif
 
-template <bool IEEE>
+template <bool IEEE, bool ACCEL_ONLY>
 __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
@@ -1126,7 +1133,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     } else if (valid) {
         force_sweep_simple<false, IEEE>(d, start, srt, nullptr, i, o, vel, c, pressure, near_pressure, acc);
     }
-    if (valid) force_store_integrate_bin(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
+    if (valid) force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
 uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
@@ -1146,20 +1153,20 @@ static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start,
                            mask, stats);
 }
 
-template <bool IEEE>
+template <bool IEEE, bool ACCEL_ONLY>
 static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                          WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias,
                          int variant, WsMask mask)
 {
     if (alias)
-        hipLaunchKernelGGL((k_force_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start, cid_srt,
-                           srt, out, accel, cid_out, count, mult);
+        hipLaunchKernelGGL((k_force_simple<true, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+                           cid_srt, srt, out, accel, cid_out, count, mult);
     else if (variant == WS_VARIANT_SIMPLE)
-        hipLaunchKernelGGL((k_force_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
+        hipLaunchKernelGGL((k_force_simple<false, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
                            cid_srt, srt, out, accel, cid_out, count, mult);
     else
-        hipLaunchKernelGGL((k_force_listed<IEEE>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), 0, s, d, start, cid_srt, srt, out,
-                           accel, cid_out, count, mask);
+        hipLaunchKernelGGL((k_force_listed<IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), 0, s, d, start, cid_srt, srt,
+                           out, accel, cid_out, count, mask);
 }
 
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
@@ -1169,12 +1176,18 @@ void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uin
     else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
 }
 
+// accel_only: nothing but accel[i] is written (see force_store_integrate_bin) -- the on-demand pass of the record views
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
-               WsMask mask)
+               WsMask mask, bool accel_only)
 {
-    if (ieee) launch_force<true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
-    else launch_force<false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+    if (accel_only) {
+        if (ieee) launch_force<true, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+        else launch_force<false, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+    } else {
+        if (ieee) launch_force<true, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+        else launch_force<false, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+    }
 }
 
 // ---------------------------------------------------------------------------------

@@ -315,6 +315,11 @@ class SlabWorker:
         self.sync()
         return int(self._L.ws_num_particles(self._h))
 
+    def set_params(self, params):
+        """ws_set_params on a slab handle (everything but the smoothing radius / container: the slab grid is fixed)."""
+        self._check(self._L.ws_set_params(self._h, C.byref(params)))
+        self.params = params
+
     def counters(self):
         """Migration counters since creation (ws_slab_counters): owned now, left, arrived, left by the far route."""
         out = (C.c_uint64 * 4)()
@@ -357,12 +362,13 @@ class SlabWorker:
 
 
 def run_loopback(positions, params, world, steps, device=0, ieee_division=False, capacity=0, ghost_capacity=0,
-                 collect_errors=False, counters=None):
+                 collect_errors=False, counters=None, change_params=None):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
     particles of all slabs merged into original-id order.  Test helper for one-GPU boxes.
     collect_errors: instead of raising, return {rank: (steps completed, exception)} for the slabs whose ws_step
     failed (the capacity tests expect every rank to fail alike).
-    counters: a dict that receives {rank: SlabWorker.counters()} taken after the last step."""
+    counters: a dict that receives {rank: SlabWorker.counters()} taken after the last step.
+    change_params: (step, params) -- every slab calls ws_set_params(params) after `step` steps."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     n = positions.shape[0]
     owner = assign(params, positions, world)
@@ -385,6 +391,10 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
                         errors.append((r, (k, e)))
                         w.close()
                         return
+            elif change_params is not None:
+                w.run(change_params[0])
+                w.set_params(change_params[1])
+                w.run(steps - change_params[0])
             else:
                 w.run(steps)
             rec, ids = w.read()
