@@ -357,6 +357,9 @@ def main():
                 "arithmetic": "f32, every operation rounded as written (no FMA contraction); sqrt / division of the pair "
                               "terms: hardware v_sqrt_f32 / v_rcp_f32 (1 ULP) -- value_ieee: correctly rounded",
                 "readback_in_timed_region": False,
+                "stored_per_step": "position, velocity, cell id (+ sorted copies, densities, accept masks); the predicted "
+                                   "position (pos + vel / 50 of the stored values) and the acceleration field of the "
+                                   "80-byte record are materialised on demand by ws_read_particles, bit-identical",
             },
             "global_steps_per_s": global_steps_per_s,
             "c3_equivalent_steps_per_s": shares * global_steps_per_s,
