@@ -181,7 +181,10 @@ ws_status ws_pin_host_buffer(ws_handle *h, void *ptr, uint64_t bytes);
 ws_status ws_unpin_host_buffer(ws_handle *h, void *ptr);
 /* The full read_vec view (src/fluid_compute.rs:478): n records of 80 bytes in
  * original-id order.  density/pressure/acceleration are the values the last step
- * computed (0 before the first step). */
+ * computed (0 before the first step).  The step itself keeps positions and velocities only: the acceleration
+ * field (read by nothing in the reference but this view) is produced here by one more pass of the force kernel over
+ * the state the last step left behind -- the same bits the step used; a frame loop that reads positions pays
+ * nothing for it. */
 ws_status ws_read_particles(ws_handle *h, ws_particle80 *out);
 /* despawn_liquid's four write_slice calls (src/fluid_compute.rs:517-524): particles
  * <- initial state from pos_xyz, index buffers <- identity. */
