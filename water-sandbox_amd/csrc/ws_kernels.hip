@@ -202,26 +202,6 @@ __device__ __forceinline__ uint32_t wave_run_atomic_inc(uint32_t *__restrict__ t
     return base + (uint32_t)(lane - hl);
 }
 
-// exclusive prefix of `v` over the 256-thread block; *total = block sum
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total)
-{
-    __shared__ uint32_t wsum[WS_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_incl_scan(v);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < WS_BLOCK / 64; w++) {
-        const uint32_t s = wsum[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + incl - v;
-}
-
 // One-pass exclusive scan (decoupled look-back): tile t publishes its aggregate, then walks back over its
 // predecessors' descriptors until it meets an inclusive prefix, and publishes its own.  Tiles take their
 // index from a ticket counter, so every predecessor of a running tile is itself running or done: the
@@ -249,6 +229,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count,
     const uint32_t tbase = tile * WS_SCAN_TILE;
     uint4 v[Q];
     uint32_t excl[Q], total = 0;
+    // all of the tile's loads first (one memory round trip, not Q of them) ...
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const uint32_t at = tbase + (q * WS_BLOCK + threadIdx.x) * 4u;
@@ -260,9 +241,29 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count,
             v[q].z = at + 2u < nitems ? count[at + 2u] : 0u;
             v[q].w = 0u;
         }
-        uint32_t chunk_total;
-        excl[q] = total + block_excl_scan(v[q].x + v[q].y + v[q].z + v[q].w, &chunk_total);
-        total += chunk_total;
+    }
+    // ... then the Q chunk scans with ONE barrier: wave scans in registers, the waves' sums through LDS
+    {
+        __shared__ uint32_t wsum[Q][WS_BLOCK / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            excl[q] = wave_incl_scan(v[q].x + v[q].y + v[q].z + v[q].w);
+            if (lane == 63) wsum[q][wave] = excl[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            uint32_t base = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < WS_BLOCK / 64; w++) {
+                const uint32_t sw = wsum[q][w];
+                if (w < wave) base += sw;
+                tot += sw;
+            }
+            excl[q] = total + base + excl[q] - (v[q].x + v[q].y + v[q].z + v[q].w);
+            total += tot;
+        }
     }
     if (threadIdx.x < 64) {
         // wave 0 looks back 64 predecessors at a time (one memory round trip per window)
