@@ -17,15 +17,16 @@ def per_kernel(kind, counter):
             per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v[-steps:]) / len(v[-steps:]) for k, v in per.items()}  # the timed window only
 fetch, write = per_kernel("fetch", "FETCH_SIZE"), per_kernel("write", "WRITE_SIZE")
-# calibration: k_reorder reads slot_tmp(4) + id_tmp(4) + cid(4) + 3 x 16 B and writes 3 x 16 + 4 + 3 x 4 B per particle
-# (plus the small cell-start lookups): a streaming kernel with a known byte count
-cal_read_expected, cal_write_expected = n * (4 + 4 + 4 + 48), n * (48 + 4 + 12)
-cal = {"reorder_fetch_raw": fetch.get("k_reorder"), "reorder_read_expected": cal_read_expected,
-       "reorder_write_raw": write.get("k_reorder"), "reorder_write_expected": cal_write_expected}
+# calibration: k_reorder<true> (the step loop's instantiation: predicted positions recomputed) reads slot_tmp(4) +
+# id_tmp(4) + cid(4) + 2 x 16 B and writes 3 x 16 + 4 + 3 x 4 B per particle (plus the small cell-start lookups and its
+# cell-mates' ids): a streaming kernel with a known byte count.  Only its two 16-B gathers fall under the half-count.
+cal_read_expected, cal_write_expected = n * (4 + 4 + 4 + 32), n * (48 + 4 + 12)
+cal = {"kernel": "k_reorder<true>", "reorder_fetch_raw": fetch.get("k_reorder<true>"), "reorder_read_expected": cal_read_expected,
+       "reorder_write_raw": write.get("k_reorder<true>"), "reorder_write_expected": cal_write_expected}
 out = {"window": {"config": cfg, "dist": dist, "warmup": warm, "steps": steps, "particles": n},
        "units": "bytes per launch, mean over the timed window",
        "fetch_raw": fetch, "write_raw": write, "calibration": cal}
-force = [k for k in fetch if k.startswith("k_force")][0]
+force = [k for k in fetch if k.startswith("k_force") and not k.endswith(", true>")][0]  # not the on-demand accel pass
 dens = [k for k in fetch if k.startswith("k_density")][0]
 out["bytes_per_launch"] = {"force_integrate_bin": 2.0 * fetch[force] + write[force],
                            "density": 2.0 * fetch[dens] + write[dens]}
