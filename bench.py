@@ -42,6 +42,7 @@ KERNEL_ALG_BYTES = {
     "force_integrate_bin": B_ALG["K5"] + B_ALG["K6"] + B_ALG["K1"],
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0  # achievable: float4 copy measured on MI355X (MI355X_MICROARCH.md, HBM section)
 C3_PARTICLES = 4194304
 SETTLED_FROM = 400     # first step of the settled window
 SETTLED_STEPS = 100
@@ -129,6 +130,9 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed):
     alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     traffic, source = (None, None) if distributed else load_traffic(config, dist, warmup, steps, dominant)
+    # the measured-bytes view SURVEY 8(d) asks for next to the algorithmic one: counter bytes per launch over this
+    # run's launch time, against the float4-copy rate measured on MI355X (MI355X_MICROARCH.md: 6.29 TB/s)
+    measured = traffic / avg_s / 1e9 if traffic and avg_s > 0 else None
     return {
         "kernel": KERNEL_LABEL[dominant],
         "bound": "hbm",
@@ -138,6 +142,8 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed):
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
         "traffic_source": source,
+        "traffic_GBps": measured,
+        "traffic_frac_of_measured_copy_bw": measured / HBM_COPY_GBS if measured else None,
         "alg_bytes_per_launch": alg_bytes,
         "avg_launch_ms": avg_s * 1e3,
         "launches_timed": cnt,
