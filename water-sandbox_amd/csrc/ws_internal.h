@@ -73,7 +73,7 @@ enum {
     WS_DYN_ERR_HALO = 4u,       // a boundary layer holds more particles than a halo message
     WS_DYN_ERR_GHOSTS = 8u      // more ghosts than the ghost range holds
 };
-enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LATE_RIGHT = 3 };
+enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LATE_RIGHT = 3, WS_RANGE_LATE_BOTH = 4 };
 #define WS_HDR_WORDS_HOST 4u  // words of a message header (ws_kernels.hip WS_HDR_WORDS)
 
 // density / force kernel family (WS_VARIANT=simple in the environment, for A/B tests)

@@ -68,36 +68,40 @@ __device__ __forceinline__ uint32_t ref_hash_key(const WsDev &d, float x, float 
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ws_n(const WsDev &d) { return d.dyn ? d.dyn[DY_N] : d.n; }
 
-// The part [lo, lo + len) of the sorted order a density / force launch covers.  Single-GPU handle: all of it.
-// Slab handle: the owned range, or one of the three pieces the halo / compute overlap cuts it into -- x is the
-// slowest axis of the sort, so "the owned layer next to a neighbour slab" is a contiguous range delimited by cell
-// starts: EARLY = the particles whose searches touch no ghost layer, LATE_LEFT / LATE_RIGHT = layers 1 / nxl-2.
-__device__ __forceinline__ void ws_range(const WsDev &d, const uint32_t *__restrict__ start, uint32_t &lo, uint32_t &len)
+// The part of the sorted order a density / force launch covers, as a span of `len` consecutive VIRTUAL offsets:
+// offset v is the particle lo + v, plus `jump` from offset `split` on.  Single-GPU handle: all of it, no jump.
+// Slab handle: the owned range, or one of the pieces the halo / compute overlap cuts it into -- x is the slowest axis
+// of the sort, so "the owned layer next to a neighbour slab" is a contiguous range delimited by cell starts: EARLY =
+// the particles whose searches touch no ghost layer, LATE_LEFT / LATE_RIGHT = layers 1 / nxl-2, LATE_BOTH = the two
+// of them in one launch (the left layer, then a jump over the early range to the right layer).
+struct WsSpan {
+    uint32_t lo, len, split, jump;
+};
+__device__ __forceinline__ WsSpan ws_span(const WsDev &d, const uint32_t *__restrict__ start)
 {
-    if (!d.dyn) {
-        lo = d.base;
-        len = d.n;
-        return;
-    }
+    WsSpan sp = {d.base, d.n, 0xFFFFFFFFu, 0u};
+    if (!d.dyn) return sp;
     const uint32_t n = d.dyn[DY_N], end = d.base + n;
-    if (d.range_sel == WS_RANGE_ALL) {
-        lo = d.base;
-        len = n;
-        return;
-    }
+    sp.len = n;
+    if (d.range_sel == WS_RANGE_ALL) return sp;
     const uint32_t a = d.has_left ? start[d.lidx[1]] : d.base;  // first particle that needs no left ghosts
     const uint32_t b = d.has_right ? start[d.lidx[2]] : end;     // first particle of the right boundary layer
     if (d.range_sel == WS_RANGE_EARLY) {
-        lo = a;
-        len = b - a;
+        sp.lo = a;
+        sp.len = b - a;
     } else if (d.range_sel == WS_RANGE_LATE_LEFT) {
-        lo = d.base;
-        len = a - d.base;
-    } else {
-        lo = b;
-        len = end - b;
+        sp.len = a - d.base;
+    } else if (d.range_sel == WS_RANGE_LATE_RIGHT) {
+        sp.lo = b;
+        sp.len = end - b;
+    } else {  // WS_RANGE_LATE_BOTH
+        sp.split = a - d.base;
+        sp.jump = b - a;
+        sp.len = (a - d.base) + (end - b);
     }
+    return sp;
 }
+__device__ __forceinline__ uint32_t span_at(const WsSpan &sp, uint32_t v) { return sp.lo + v + (v >= sp.split ? sp.jump : 0u); }
 
 // ---------------------------------------------------------------------------------
 // uploads
@@ -786,10 +790,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_density_simple(WsDev d, const uint
                                                              const uint32_t *__restrict__ cid_srt, WsSorted srt,
                                                              const uint8_t *__restrict__ mult)
 {
-    uint32_t lo, len;
-    ws_range(d, start, lo, len);
-    const uint32_t i = lo + blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= lo + len) return;
+    const WsSpan sp = ws_span(d, start);
+    const uint32_t v = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (v >= sp.len) return;
+    const uint32_t i = span_at(sp, v);
     float density = 0.f, near_density = 0.f;
     density_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, srt.pred(i), (int)cid_srt[i], density, near_density);
     density_store(density, near_density, i, srt);
@@ -801,10 +805,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
                                                            float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                            uint32_t *__restrict__ count, const uint8_t *__restrict__ mult)
 {
-    uint32_t lo, len;
-    ws_range(d, start, lo, len);
-    const uint32_t i = lo + blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (i >= lo + len) return;
+    const WsSpan sp = ws_span(d, start);
+    const uint32_t v = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (v >= sp.len) return;
+    const uint32_t i = span_at(sp, v);
     const float4 o = srt.pred(i);    // w = own density
     const float4 vel = srt.vel(i);   // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
@@ -922,13 +926,12 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
                                                          WsMask mask, uint32_t *__restrict__ stats)
 {
     __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
-    uint32_t lo, len;
-    ws_range(d, start, lo, len);
-    const uint32_t ntiles = (len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
+    const WsSpan sp = ws_span(d, start);
+    const uint32_t ntiles = (sp.len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
     if (blockIdx.x >= ntiles) return;
-    const uint32_t i = lo + xcd_tile(blockIdx.x, ntiles) * ND_P + threadIdx.x;
-    const bool valid = i < lo + len;
-    const uint32_t iv = valid ? i : lo + len - 1u;
+    const uint32_t v = xcd_tile(blockIdx.x, ntiles) * ND_P + threadIdx.x;
+    const bool valid = v < sp.len;
+    const uint32_t iv = span_at(sp, valid ? v : sp.len - 1u), i = iv;  // lanes past the end shadow the last particle
     const float4 o = make_float4(sxyz.x[iv], sxyz.y[iv], sxyz.z[iv], 0.f);  // the planar copy: coalesced, same bits
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
@@ -992,13 +995,12 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     // per-lane run table: candidate numbers [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
     __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
     __shared__ uint32_t t_delta[9 * NF_P];
-    uint32_t lo, len;
-    ws_range(d, start, lo, len);
-    const uint32_t ntiles = (len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
+    const WsSpan sp = ws_span(d, start);
+    const uint32_t ntiles = (sp.len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
     if (blockIdx.x >= ntiles) return;
-    const uint32_t i = lo + xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
-    const bool valid = i < lo + len;
-    const uint32_t iv = valid ? i : lo + len - 1u;
+    const uint32_t v = xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
+    const bool valid = v < sp.len;
+    const uint32_t iv = span_at(sp, valid ? v : sp.len - 1u), i = iv;  // lanes past the end shadow the last particle
     const float4 o = srt.pred(iv);   // w = own density
     const float4 vel = srt.vel(iv);  // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
