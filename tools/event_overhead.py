@@ -1,0 +1,12 @@
+import sys, os, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import water_sandbox_amd as ws
+pos, params = ws.workloads.make_workload("c3", "cloud")
+for mask, label in ((0, "no events"), ((1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"]), "K4+K5 events"), (1 << ws.fluid.KERNEL_IDS["force_integrate_bin"], "K5 events"), (0xFFFFFFFF, "all events")):
+    for rep in range(2):
+        w = ws.FluidWorker(pos, params, profile=True)
+        w.profile_select(mask)
+        w.run(5); w.sync()
+        t0 = time.perf_counter(); w.run(20); w.sync(); t = time.perf_counter() - t0
+        print(label, "%.4f ms/step" % (t / 20 * 1e3), flush=True)
+        w.close()

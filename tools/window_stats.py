@@ -28,7 +28,7 @@ for name, rows in sorted(per.items()):
     if len(d) < warm + steps:
         continue  # not a per-step kernel
     for label, (a, b) in windows.items():
-        if len(d) >= b:
+        if b > a and len(d) >= b:
             w = d[a:b]
             out["windows"].setdefault(label, {})[name] = {"launches": len(w), "mean_us": sum(w) / len(w) / 1e3,
                                                           "min_us": min(w) / 1e3, "max_us": max(w) / 1e3}

@@ -282,6 +282,31 @@ struct Prof {
     }
 };
 
+// The same for ONE kernel launch: the pair goes to the launch (hipExtLaunchKernelGGL start / stop events) instead of
+// being recorded around it.
+struct ProfLaunch {
+    ws_handle *h;
+    bool on;
+    WsEventPair p{};
+    ProfLaunch(ws_handle *h_, uint32_t k) : h(h_), on((h_->flags & WS_FLAG_PROFILE) != 0 && ((h_->prof_mask >> k) & 1u))
+    {
+        if (!on) return;
+        p.kernel = k;
+        p.a = get_event(h);
+        p.b = get_event(h);
+        if (!p.a || !p.b) {
+            if (p.a) h->pool.push_back(p.a);
+            if (p.b) h->pool.push_back(p.b);
+            on = false;
+        }
+    }
+    const WsEventPair *events() const { return on ? &p : nullptr; }
+    ~ProfLaunch()
+    {
+        if (on) h->pending.push_back(p);
+    }
+};
+
 void drain_profile(ws_handle *h)
 {
     for (auto &p : h->pending) {
@@ -315,13 +340,15 @@ void enqueue_step(ws_handle *h)
         wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
     }
     {
-        Prof p(h, WS_K_DENSITY);
-        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->ieee, h->stats, h->mask, h->sxyz);
+        // one launch each: timed by events the launch itself carries (no event packets between the kernels)
+        ProfLaunch p(h, WS_K_DENSITY);
+        wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->ieee, h->stats, h->mask, h->sxyz,
+                    p.events());
     }
     {
-        Prof p(h, WS_K_FORCE);
+        ProfLaunch p(h, WS_K_FORCE);
         wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->ieee, h->mask, false);
+                  h->variant, h->ieee, h->mask, false, p.events());
     }
     h->pred_stale = true;   // the epilogue stores position and velocity only (k_reorder)
     h->accel_stale = true;  // ... and no accelerations (refresh_accel)

@@ -256,11 +256,12 @@ void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const 
                  bool recompute_pred);
 void wsk_refresh_pred(hipStream_t s, const WsDev &d, WsSoA cur);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
-                 const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz);
+                 const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz,
+                 const WsEventPair *ev = nullptr);
 uint32_t wsk_mask_words(void);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
-               WsMask mask, bool accel_only);
+               WsMask mask, bool accel_only, const WsEventPair *ev = nullptr);
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
 void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,

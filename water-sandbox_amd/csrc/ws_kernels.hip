@@ -19,6 +19,8 @@
 
 #include "ws_internal.h"
 
+#include <hip/hip_ext.h>  // hipExtLaunchKernelGGL: a launch with its own start / stop events
+
 
 #pragma clang fp contract(off)
 
@@ -1141,55 +1143,63 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
 
 uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
 
+// ev (optional): the launch carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch packet's
+// completion signal is time-stamped) -- per-kernel timing without separate event packets in front of and behind the
+// kernel, each of which costs the stream 7-9 us
+#define WS_LAUNCH(kernel, grid, block, s, ev, ...)                                                          \
+    do {                                                                                                    \
+        if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, (ev)->a, (ev)->b, 0, __VA_ARGS__);         \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);                                    \
+    } while (0)
+
 template <bool IEEE>
 static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
-                           const uint8_t *mult, bool alias, int variant, uint32_t *stats, WsMask mask, WsXYZ sxyz)
+                           const uint8_t *mult, bool alias, int variant, uint32_t *stats, WsMask mask, WsXYZ sxyz,
+                           const WsEventPair *ev)
 {
     if (alias)
-        hipLaunchKernelGGL((k_density_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                           cid_srt, srt, mult);
+        WS_LAUNCH((k_density_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
     else if (variant == WS_VARIANT_SIMPLE)
-        hipLaunchKernelGGL((k_density_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                           cid_srt, srt, mult);
+        WS_LAUNCH((k_density_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
     else
-        hipLaunchKernelGGL((k_density_listed<IEEE>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), 0, s, d, start, cid_srt, srt, sxyz,
-                           mask, stats);
+        WS_LAUNCH((k_density_listed<IEEE>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
 }
 
 template <bool IEEE, bool ACCEL_ONLY>
 static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                          WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias,
-                         int variant, WsMask mask)
+                         int variant, WsMask mask, const WsEventPair *ev)
 {
     if (alias)
-        hipLaunchKernelGGL((k_force_simple<true, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                           cid_srt, srt, out, accel, cid_out, count, mult);
+        WS_LAUNCH((k_force_simple<true, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt,
+                  srt, out, accel, cid_out, count, mult);
     else if (variant == WS_VARIANT_SIMPLE)
-        hipLaunchKernelGGL((k_force_simple<false, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, start,
-                           cid_srt, srt, out, accel, cid_out, count, mult);
+        WS_LAUNCH((k_force_simple<false, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt,
+                  srt, out, accel, cid_out, count, mult);
     else
-        hipLaunchKernelGGL((k_force_listed<IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), 0, s, d, start, cid_srt, srt,
-                           out, accel, cid_out, count, mask);
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask);
 }
 
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
-                 const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz)
+                 const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz,
+                 const WsEventPair *ev)
 {
-    if (ieee) launch_density<true>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
-    else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz);
+    if (ieee) launch_density<true>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev);
+    else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev);
 }
 
 // accel_only: nothing but accel[i] is written (see force_store_integrate_bin) -- the on-demand pass of the record views
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
-               WsMask mask, bool accel_only)
+               WsMask mask, bool accel_only, const WsEventPair *ev)
 {
     if (accel_only) {
-        if (ieee) launch_force<true, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
-        else launch_force<false, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+        if (ieee) launch_force<true, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
+        else launch_force<false, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
     } else {
-        if (ieee) launch_force<true, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
-        else launch_force<false, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask);
+        if (ieee) launch_force<true, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
+        else launch_force<false, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
     }
 }
 
