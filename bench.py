@@ -231,9 +231,10 @@ def main():
         def make_worker(ieee=False):
             return ws.FluidWorker(pos, params, device=local_rank, profile=True, ieee_division=ieee)
 
-    # HIP events bracket only the two neighbour kernels inside the timed regions (4 records per step, on the
-    # library's stream): one of them is the dominant kernel, and bracketing all five launches costs several
-    # per cent of a sub-millisecond step
+    # HIP events time only the two neighbour kernels inside the timed regions (the start / stop events each launch
+    # carries, on the library's stream; a slab step that splits them into early / late ranges records events around
+    # the group): one of them is the dominant kernel, and timing all five launches costs several per cent of a
+    # sub-millisecond step
     neighbour_mask = (1 << ws.fluid.KERNEL_IDS["force_integrate_bin"]) | (1 << ws.fluid.KERNEL_IDS["density"])
 
     def barrier(worker):
