@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer: what per-kernel timing costs the step.  C3 cloud, steps 5..25, with no kernels timed, with the two
+neighbour kernels timed (what bench.py does), with K5 alone, and with all five -- ms per step, twice each."""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import water_sandbox_amd as ws
