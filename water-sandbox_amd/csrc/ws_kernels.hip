@@ -895,10 +895,12 @@ template <class Push, class Phase2, class Note>
 __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t j, uint32_t e, uint32_t &cnt,
                                               WsXYZ p, Push &&push, Phase2 &&phase2, Note &&note)
 {
+    // the walk keeps two numbers per lane: the byte offset of the next candidate in the planes (32-bit, from the three
+    // uniform plane bases: no 64-bit address arithmetic) and how many candidates of the run remain
+    uint32_t off = j * 4u;
+    int32_t rem = (int32_t)(e - j);
     for (;;) {
-        while (j < e && cnt < (uint32_t)ND_K) {
-            // 32-bit byte offsets from the three (uniform) plane bases: one shift instead of three 64-bit adds
-            const uint32_t off = j * 4u;
+        while (rem > 0 && cnt < (uint32_t)ND_K) {
             const nd_f4 X = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.x) + off);
             const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.y) + off);
             const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.z) + off);
@@ -908,15 +910,16 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
             uint32_t bits = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const bool acc = (j + u < e) && !(d2[u] > d.d2_accept);
+                const bool acc = (u < rem) && !(d2[u] > d.d2_accept);  // (u < rem: the candidate belongs to the run)
                 push(cnt, d2[u]);  // branch-free: store always, advance the slot on accept
                 cnt += acc ? 1u : 0u;
                 bits |= (acc ? 1u : 0u) << u;
             }
-            note(min(4u, e - j), bits);
-            j += 4;
+            note((uint32_t)min(4, rem), bits);
+            off += 16u;
+            rem -= 4;
         }
-        if (!__ballot(cnt >= (uint32_t)ND_K && j < e)) break;  // nobody is blocked on a full list
+        if (!__ballot(cnt >= (uint32_t)ND_K && rem > 0)) break;  // nobody is blocked on a full list
         phase2(cnt);
         cnt = 0;
     }
@@ -938,22 +941,24 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
     float density = 0.f, near_density = 0.f;
-    // accept mask: bit `seq` = candidate number seq in visit order.  Trips append up to 4 bits to a 64-bit
-    // accumulator; a full low word goes out (coalesced across lanes).
-    unsigned long long acc64 = 0;
-    uint32_t seq = 0;
+    // accept mask: bit `seq` = candidate number seq in visit order.  Trips append up to 4 bits to a 32-bit
+    // accumulator; when a trip crosses into the next word the full word goes out (coalesced across lanes) and the
+    // bits that spilled over start the next one -- the crossing is the rare path, one trip in eight.
+    uint32_t acc32 = 0;
+    uint32_t pos = 0, word = 0;  // candidates seen so far = 32 * word + pos
     uint32_t *mrow = mask.words + (iv - d.base);
     auto push = [&](uint32_t slot, float d2) { list[slot * ND_P + threadIdx.x] = d2; };
     auto phase2 = [&](uint32_t cnt) {
         for (uint32_t k = 0; k < cnt; k++) density_pair<IEEE>(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
     };
     auto note = [&](uint32_t nvalid, uint32_t bits) {
-        acc64 |= (unsigned long long)bits << (seq & 31u);
-        const uint32_t w0 = seq >> 5;
-        seq += nvalid;
-        if ((seq >> 5) != w0) {
-            if (w0 < ND_MASK_WORDS) mrow[(size_t)w0 * mask.stride] = (uint32_t)acc64;
-            acc64 >>= 32;
+        acc32 |= bits << pos;
+        pos += nvalid;
+        if (pos >= 32u) {  // pos was >= 28, so the shift below is by 1..4
+            if (word < ND_MASK_WORDS) mrow[(size_t)word * mask.stride] = acc32;
+            pos -= 32u;
+            acc32 = bits >> (nvalid - pos);  // the bits that spilled over: the trip's last `pos` ones
+            word++;
         }
     };
     uint32_t cnt = 0;
@@ -975,8 +980,8 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     }
     phase2(cnt);
     if (valid) {
-        if ((seq & 31u) && (seq >> 5) < ND_MASK_WORDS) mrow[(size_t)(seq >> 5) * mask.stride] = (uint32_t)acc64;
-        if (seq > 32u * ND_MASK_WORDS) atomicAdd(&stats[0], 1u);  // rare by construction: one counter is enough
+        if (pos && word < ND_MASK_WORDS) mrow[(size_t)word * mask.stride] = acc32;
+        if (32u * word + pos > 32u * ND_MASK_WORDS) atomicAdd(&stats[0], 1u);  // rare by construction: one counter is enough
         density_store(density, near_density, i, srt);
     }
 }
