@@ -899,8 +899,9 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
     // uniform plane bases: no 64-bit address arithmetic) and how many candidates of the run remain
     uint32_t off = j * 4u;
     int32_t rem = (int32_t)(e - j);
+    bool more = rem > 0;
     for (;;) {
-        while (rem > 0 && cnt < (uint32_t)ND_K) {
+        while (more && cnt < (uint32_t)ND_K) {
             const nd_f4 X = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.x) + off);
             const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.y) + off);
             const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.z) + off);
@@ -917,9 +918,10 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
             }
             note((uint32_t)min(4, rem), bits);
             off += 16u;
+            more = rem > 4;
             rem -= 4;
         }
-        if (!__ballot(cnt >= (uint32_t)ND_K && rem > 0)) break;  // nobody is blocked on a full list
+        if (!__ballot(cnt >= (uint32_t)ND_K && more)) break;  // nobody is blocked on a full list
         phase2(cnt);
         cnt = 0;
     }
