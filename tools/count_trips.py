@@ -1,0 +1,13 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np
+import water_sandbox_amd as ws
+L = ws.fluid.load_library()
+pos, params = ws.workloads.make_workload("c3", "cloud")
+for warm in (10, 400):
+    w = ws.FluidWorker(pos, params); w.run(warm); w.sync()
+    out = (C.c_uint32 * 8)(); L.ws_exp_read(out)
+    w.run(4); w.sync(); L.ws_exp_read(out)
+    waves = pos.shape[0] / 64 * 4
+    print("warm", warm, "wave-trips per wave %.1f" % (out[1] / waves), "active lanes per trip %.1f" % (out[3] / max(out[1], 1)), "phase-2 iterations per wave %.1f" % (out[2] / waves), "flushes per wave %.1f" % (out[4] / waves))
+    w.close()
