@@ -974,7 +974,13 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #ifdef WS_EXP_COUNT
         { uint32_t m = cnt; for (int sh = 32; sh >= 1; sh >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sh, 64)); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_exp[2], m); atomicAdd(&g_exp[4], 1u); } }
 #endif
-        for (uint32_t k = 0; k < cnt; k++) density_pair<IEEE>(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
+        uint32_t k = 0;
+        for (; k + 2u <= cnt; k += 2u) {  // two list entries per pass: their LDS reads and square roots overlap
+            const float a = list[k * ND_P + threadIdx.x], b = list[(k + 1u) * ND_P + threadIdx.x];
+            density_pair<IEEE>(d, a, density, near_density, 1u);
+            density_pair<IEEE>(d, b, density, near_density, 1u);
+        }
+        if (k < cnt) density_pair<IEEE>(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
     };
     auto note = [&](uint32_t nvalid, uint32_t bits) {
         acc32 |= bits << pos;
