@@ -1128,6 +1128,9 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         uint32_t avail = 0, rest = 0, wbase = 0, widx = 0;
         uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
         auto advance = [&]() -> bool {
+#ifdef WS_EXP_COUNT
+            { const unsigned long long act = __ballot(true); if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) { atomicAdd(&g_exp[7], 1u); } }
+#endif
             while (rest == 0u) {
                 if (widx >= nwords) return false;
                 rest = wnext;
@@ -1161,6 +1164,9 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         float4 q_next = srt.pred_near(j1), nvel_next = srt.vel_near(j1);
         bool have1 = have0 && next(j2);
         while (have0) {
+#ifdef WS_EXP_COUNT
+            { const unsigned long long act = __ballot(true); if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) { atomicAdd(&g_exp[5], 1u); atomicAdd(&g_exp[6], (uint32_t)__popcll(act)); } }
+#endif
             const float4 q = q_next, nvel = nvel_next;
             q_next = srt.pred_near(j2);
             nvel_next = srt.vel_near(j2);
