@@ -13,5 +13,5 @@ for warm in (10, 400):
     out = (C.c_uint32 * 8)(); L.ws_exp_read(out)
     w.run(4); w.sync(); L.ws_exp_read(out)
     waves = pos.shape[0] / 64 * 4
-    print("warm", warm, "| K5 iterator: wave-trips per wave %.1f, active lanes per trip %.1f, advance() entries per wave %.1f |" % (out[5] / waves, out[6] / max(out[5], 1), out[7] / waves), "wave-trips per wave %.1f" % (out[1] / waves), "active lanes per trip %.1f" % (out[3] / max(out[1], 1)), "phase-2 iterations per wave %.1f" % (out[2] / waves), "flushes per wave %.1f" % (out[4] / waves))
+    print("warm", warm, "| K5 iterator: wave-trips per wave %.1f, active lanes per trip %.1f |" % (out[5] / waves, out[6] / max(out[5], 1)), "wave-trips per wave %.1f" % (out[1] / waves), "active lanes per trip %.1f" % (out[3] / max(out[1], 1)), "phase-2 iterations per wave %.1f" % (out[2] / waves), "flushes per wave %.1f" % (out[4] / waves))
     w.close()

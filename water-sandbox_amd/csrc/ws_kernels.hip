@@ -1121,16 +1121,15 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
                              acc, 1u);
         }
       } else {
-        // Iterator over the set bits of the mask = the neighbours in visit order.  `avail` holds the pending
-        // bits of the current word that belong to the current run, so the per-neighbour path is ffs + clear +
-        // add; everything rare (next word, next run, dropping the particle's own bit -- simulation.wgsl:232
-        // `particle_index == neighbour_index`) happens in advance().
-        uint32_t avail = 0, rest = 0, wbase = 0, widx = 0;
+        // Iterator over the set bits of the mask = the neighbours in visit order (the particle's own bit is dropped
+        // when its word is fetched -- simulation.wgsl:232 `particle_index == neighbour_index`).
+        uint32_t rest = 0, wbase = 0, widx = 0;
         uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
-        auto advance = [&]() -> bool {
-#ifdef WS_EXP_COUNT
-            { const unsigned long long act = __ballot(true); if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) { atomicAdd(&g_exp[7], 1u); } }
-#endif
+        // One pending-bits register per lane: a neighbour is ffs + clear + one compare against the end of the current
+        // run.  The two rare steps -- next mask word, next run -- are short and independent, so a wave in which some
+        // lane takes one of them on almost every trip (9 words and 9 runs per lane in the dense state) pays ~15
+        // instructions for it, not the ~40 of a combined word-and-run segment computation.
+        auto next = [&](uint32_t &j) -> bool {
             while (rest == 0u) {
                 if (widx >= nwords) return false;
                 rest = wnext;
@@ -1139,22 +1138,14 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
                 widx++;
                 wnext = widx < nwords ? mrow[(size_t)widx * mask.stride] : 0u;
             }
-            const uint32_t s0 = wbase + (uint32_t)__ffs((int)rest) - 1u;  // lowest pending candidate number
-            while (s0 >= end_r) {
+            const uint32_t sc = wbase + (uint32_t)__ffs((int)rest) - 1u;
+            rest &= rest - 1u;
+            while (sc >= end_r) {
                 run++;
                 end_r = t_end[run * NF_P + threadIdx.x];
                 delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
             }
-            const uint32_t lim = end_r - wbase;  // > s0 - wbase: the run owns at least that bit of this word
-            const uint32_t m = lim >= 32u ? 0xFFFFFFFFu : (1u << lim) - 1u;
-            avail = rest & m;
-            rest &= ~m;
-            return true;
-        };
-        auto next = [&](uint32_t &j) -> bool {
-            if (avail == 0u && !advance()) return false;
-            j = wbase + (uint32_t)__ffs((int)avail) - 1u + delta_r;
-            avail &= avail - 1u;
+            j = sc + delta_r;
             return true;
         };
         // Software pipeline: while neighbour k computes, the records of neighbour k+1 are in flight and the
