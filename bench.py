@@ -122,9 +122,18 @@ def load_traffic(config, dist, warmup, steps, kernel):
         return None, None
 
 
-def roofline_of(prof, owned, config, dist, warmup, steps, distributed):
-    """The roofline object of one timed window from the library's HIP-event brackets around the two neighbour kernels."""
-    dominant = max(("density", "force_integrate_bin"), key=lambda k: prof[k][0])
+NEIGHBOUR_KERNELS = ("density", "force_integrate_bin")
+
+
+def dominant_kernel(*profs):
+    """The neighbour kernel with the most time over ALL the timed windows of the run (in the sparse first window K4 and
+    K5 are within 2 % of each other and would swap places from run to run; in the settled state K5 leads by a third)."""
+    return max(NEIGHBOUR_KERNELS, key=lambda k: sum(p[k][0] / max(p[k][1], 1) * w for p, w in profs))
+
+
+def roofline_of(prof, owned, config, dist, warmup, steps, distributed, dominant):
+    """The roofline object of one timed window from the HIP events of the two neighbour kernels' launches, for the run's
+    dominant kernel; the other neighbour kernel's figures ride along under `other`."""
     ms, cnt = prof[dominant]
     avg_s = ms / max(cnt, 1) * 1e-3
     alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
@@ -133,8 +142,16 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed):
     # the measured-bytes view SURVEY 8(d) asks for next to the algorithmic one: counter bytes per launch over this
     # run's launch time, against the float4-copy rate measured on MI355X (MI355X_MICROARCH.md: 6.29 TB/s)
     measured = traffic / avg_s / 1e9 if traffic and avg_s > 0 else None
+    other = [k for k in NEIGHBOUR_KERNELS if k != dominant][0]
+    o_ms, o_cnt = prof[other]
+    o_avg = o_ms / max(o_cnt, 1) * 1e-3
+    o_alg = KERNEL_ALG_BYTES[other] * owned
     return {
         "kernel": KERNEL_LABEL[dominant],
+        "dominance": "most time over all timed windows of this run",
+        "other": {"kernel": KERNEL_LABEL[other], "avg_launch_ms": o_avg * 1e3, "alg_bytes_per_launch": o_alg,
+                  "achieved": o_alg / o_avg / 1e9 if o_avg > 0 else 0.0,
+                  "frac": (o_alg / o_avg / 1e9 if o_avg > 0 else 0.0) / HBM_PEAK_GBS},
         "bound": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
@@ -263,14 +280,18 @@ def main():
     elapsed, prof = timed_window(worker, args.steps)
     owned = worker.num_owned() if distributed else n_global
     breakdown = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]}
-    roof = roofline_of(prof, owned, cfg_name, args.dist, args.warmup, args.steps, distributed)
 
     settled = None
+    s_prof = None
     done = args.warmup + args.steps
     if not args.no_settled and done <= SETTLED_FROM:
         worker.run(SETTLED_FROM - done)
         s_elapsed, s_prof = timed_window(worker, SETTLED_STEPS)
         s_owned = worker.num_owned() if distributed else n_global
+    # one dominant kernel for the whole run: per-launch means weighted by the windows' step counts
+    dominant = dominant_kernel(*([(prof, args.steps)] + ([(s_prof, SETTLED_STEPS)] if s_prof is not None else [])))
+    roof = roofline_of(prof, owned, cfg_name, args.dist, args.warmup, args.steps, distributed, dominant)
+    if s_prof is not None:
         settled = {
             "window": "steps %d..%d of the same trajectory" % (SETTLED_FROM, SETTLED_FROM + SETTLED_STEPS),
             "warmup": SETTLED_FROM,
@@ -278,7 +299,7 @@ def main():
             "ms_per_step": s_elapsed / SETTLED_STEPS * 1e3,
             "global_steps_per_s": SETTLED_STEPS / s_elapsed,
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in s_prof.items() if v[1]},
-            "roofline": roofline_of(s_prof, s_owned, cfg_name, args.dist, SETTLED_FROM, SETTLED_STEPS, distributed),
+            "roofline": roofline_of(s_prof, s_owned, cfg_name, args.dist, SETTLED_FROM, SETTLED_STEPS, distributed, dominant),
         }
     if args.breakdown and not distributed and rank == 0:
         worker.profile_select(0xFFFFFFFF)
