@@ -1018,8 +1018,8 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 }
 
 #ifndef NF_WORDSYNC_MAX
-#define NF_WORDSYNC_MAX 10  // mask words per particle up to which a wave takes the word-synchronous walk (C3 settled, K5:
-#endif                      // 1-5: 0.926, 8: 0.911, 10: 0.891, 12: 0.897, 16: 1.010 ms; no effect in the sparse state)
+#define NF_WORDSYNC_MAX 8  // mask words per particle up to which a wave takes the word-synchronous walk.  Settled K5 at
+#endif                     // 8 / 10 words: C3 0.911 / 0.891 ms, but C2 0.068 / 0.085 ms -- 8 is the safe side
 #ifndef NF_P
 #define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
 #endif
