@@ -66,6 +66,10 @@ extern "C" {
     fn ws_last_error(h: *mut WsHandle) -> *const c_char;
 }
 
+// ws_status values the shim tells apart (include/wsfluid.h)
+const WS_ERR_INVALID_ARG: c_int = 1;
+const WS_ERR_OUT_OF_MEMORY: c_int = 3;
+
 fn check(h: *mut WsHandle, status: c_int, what: &str) {
     if status != 0 {
         let text = unsafe { CStr::from_ptr(ws_last_error(h)) }.to_string_lossy().into_owned();
@@ -123,6 +127,7 @@ pub struct HipFluidWorker {
     positions: Vec<f32>,   // n * 3, original-id order; page-locked for the lifetime of the worker
     readback_in_flight: bool,
     have_positions: bool,
+    rejected_radius: Option<f32>, // last smoothing radius ws_set_params refused (logged once)
 }
 // A ws_handle is not thread-affine (every entry point selects its device); ResMut serialises the calls.
 unsafe impl Send for HipFluidWorker {}
@@ -189,7 +194,7 @@ impl Plugin for FluidComputePlugin {
         let bytes = (positions.len() * std::mem::size_of::<f32>()) as u64;
         check(handle, unsafe { ws_pin_host_buffer(handle, positions.as_mut_ptr() as *mut c_void, bytes) }, "ws_pin_host_buffer");
 
-        app.insert_resource(HipFluidWorker { handle, params, positions, readback_in_flight: false, have_positions: false })
+        app.insert_resource(HipFluidWorker { handle, params, positions, readback_in_flight: false, have_positions: false, rejected_radius: None })
             .add_systems(PostUpdate, (
                 prepare_step.in_set(ShaderPhysicsSet::Prepare), // where the reference unmaps its staging buffers (:395)
                 run_step.in_set(ShaderPhysicsSet::Pass),        // AppComputeWorker::run (:396)
@@ -284,8 +289,22 @@ fn update(
     }
     let mut params = worker.params;
     fill_uniforms(&mut params, &fluid_props, &gravity);
-    check(h, unsafe { ws_set_params(h, &params) }, "ws_set_params"); // the three worker.write calls, :479-481
-    worker.params = params;
+    // the three worker.write calls, :479-481.  A parameter set the library cannot take (a HUD key press can make the
+    // smoothing radius zero or negative, src/hud.rs:135-138; WS_ERR_INVALID_ARG / WS_ERR_OUT_OF_MEMORY) must not take
+    // the app down: the library keeps its previous parameters, and so does the worker; say so once per rejected value.
+    let status = unsafe { ws_set_params(h, &params) };
+    if status == 0 {
+        worker.params = params;
+        worker.rejected_radius = None;
+    } else if status == WS_ERR_INVALID_ARG || status == WS_ERR_OUT_OF_MEMORY {
+        if worker.rejected_radius != Some(params.smoothing_radius) {
+            let text = unsafe { CStr::from_ptr(ws_last_error(h)) }.to_string_lossy().into_owned();
+            warn!("ws_set_params rejected (status {status}: {text}); keeping the previous parameters");
+            worker.rejected_radius = Some(params.smoothing_radius);
+        }
+    } else {
+        check(h, status, "ws_set_params");
+    }
     if !worker.have_positions {
         return; // nothing has been stepped yet
     }

@@ -33,3 +33,30 @@ def refcheck(ws):
     """The TEST-ONLY build of the library that also contains the reference-order validation kernels
     (tests/libwsfluid_refcheck.so; the product library refuses WS_FLAG_REFERENCE_ORDER)."""
     return ws.fluid.bind_library(ws.build.build_refcheck_library())
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Tolerance-usage report: every float comparison against the oracle made in this session (case, arithmetic,
+    field, L-inf error, noise unit, tolerance, error / tolerance).  Written where gpurun brings it back from the GPU
+    box; the copy judged per round is profiles/rNN/parity_report.json."""
+    import json
+
+    from util import PARITY_REPORT
+
+    if not PARITY_REPORT:
+        return
+    path = os.environ.get("WS_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_report.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        worst = {}
+        for r in PARITY_REPORT:
+            k = "%s/%s" % (r["field"], r["arithmetic"])
+            if r["error_over_tolerance"] >= worst.get(k, {"error_over_tolerance": -1.0})["error_over_tolerance"]:
+                worst[k] = r
+        with open(path, "w") as f:
+            json.dump({"policy": "tolerance = 4 x L-inf(oracle - oracle with reversed neighbour order) + 4 ulp x max|field| "
+                                 "(8 x for the golden one-step tests); bitwise records have tolerance 0",
+                       "comparisons": len(PARITY_REPORT), "worst_per_field_and_arithmetic": worst,
+                       "records": PARITY_REPORT}, f, indent=1)
+    except OSError:
+        pass

@@ -43,7 +43,8 @@ def test_c2_full_size_one_step_against_the_oracle(oracle, ws, dist, presteps, ie
     assert np.array_equal(np.sort(perm), np.arange(pos.shape[0], dtype=np.uint32))
     assert np.array_equal(keys[perm], sorted_want)
     assert np.array_equal(off, off_want)
-    assert_particles_close(got, want, reorder_noise_tolerances(want, rev), "c2 %s +%d" % (dist, presteps))
+    assert_particles_close(got, want, reorder_noise_tolerances(want, rev), "c2 %s +%d" % (dist, presteps),
+                           "ieee-division" if ieee else "hw-rcp-sqrt")
 
 
 # ------------------------------------------------------------------------------------------------

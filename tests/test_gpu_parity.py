@@ -41,7 +41,7 @@ def _teacher_forced(O, ws, pos, params, steps, label, ieee=False):
         got = worker.read_vec("particles")
         rev = oracle_one_step(O, orc, state, reverse=True)
         tol = reorder_noise_tolerances(want, rev)
-        assert_particles_close(got, want, tol, "%s step %d" % (label, s))
+        assert_particles_close(got, want, tol, "%s step %d" % (label, s), "ieee-division" if ieee else "hw-rcp-sqrt")
         assert np.array_equal(worker.read_positions(), got["position"][:, :3])
         state = want
     worker.close()

@@ -9,11 +9,13 @@ LIB = os.path.join(HERE, "libwsfluid.so")
 
 SOURCES = ["ws_kernels.hip", "ws_api.cpp", "ws_rccl.cpp"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
-# Test-only build of the same sources plus the reference-order validation kernels (ws_refcheck.inc, a literal
-# HIP restatement of the reference's six WGSL passes used by the tests as a second, independent restatement).  It lives under
-# tests/, is built by __graft_entry__.build() and is never loaded by the product package.
+# Test-only build of the same sources plus the reference-order validation mode (tests/refcheck/: a literal HIP
+# restatement of the reference's six WGSL passes and its host glue, used by the tests as a second, independent
+# restatement).  Sources and binary live under tests/; it is built by __graft_entry__.build() and is never loaded by the
+# product package.  Without -DWS_WITH_REFCHECK the product sources contain no reference-order code path at all.
+REFCHECK_DIR = os.path.join(ROOT, "tests", "refcheck")
 REFCHECK_LIB = os.path.join(ROOT, "tests", "libwsfluid_refcheck.so")
-REFCHECK_EXTRA = [os.path.join(CSRC, "ws_refcheck.inc")]
+REFCHECK_EXTRA = [os.path.join(REFCHECK_DIR, f) for f in ("ws_refcheck.inc", "ws_refcheck_host.inc", "ws_refcheck.h")]
 
 # -ffp-contract=off: every float op in the kernels is one IEEE binary32 op, written in the
 # reference WGSL's evaluation order (no FMA contraction), see ws_kernels.hip.
@@ -63,7 +65,7 @@ def build_refcheck_library(force=False, verbose=False):
     """Compile the TEST-ONLY library (product sources + the reference-order validation kernels)."""
     if not force and not _stale(REFCHECK_LIB, REFCHECK_EXTRA):
         return REFCHECK_LIB
-    return _compile(REFCHECK_LIB, ["-DWS_WITH_REFCHECK"], verbose)
+    return _compile(REFCHECK_LIB, ["-DWS_WITH_REFCHECK", "-I", REFCHECK_DIR], verbose)
 
 
 if __name__ == "__main__":

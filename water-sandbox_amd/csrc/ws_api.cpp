@@ -22,7 +22,6 @@ thread_local std::string g_create_error;
 void slab_free(ws_handle *h);          // ws_slab.inc
 ws_status slab_step(ws_handle *h);     // ws_slab.inc
 ws_status slab_settle(ws_handle *h);   // ws_slab.inc
-ws_status ref_upload_positions(ws_handle *h, const float *pos_xyz);
 
 ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
 {
@@ -241,6 +240,18 @@ ws_status ensure_stage(ws_handle *h, size_t bytes)
     return WS_OK;
 }
 
+// The test-only build also contains a validation mode that runs the reference's six passes literally
+// (tests/refcheck/): its handles are handed over at the top of every entry point.  Nothing of it exists in the product.
+#ifdef WS_WITH_REFCHECK
+#include "ws_refcheck_host.inc"
+#define WS_REF_DISPATCH(h, call)       \
+    do {                               \
+        if ((h)->refmode) return call; \
+    } while (0)
+#else
+#define WS_REF_DISPATCH(h, call) ((void)0)
+#endif
+
 // ---- profiling ---------------------------------------------------------------------
 hipEvent_t get_event(ws_handle *h)
 {
@@ -354,29 +365,6 @@ void enqueue_step(ws_handle *h)
     h->accel_stale = true;  // ... and no accelerations (refresh_accel)
 }
 
-// reference-order mode: (re)load the by-id arrays from 80-byte records
-ws_status ref_load(ws_handle *h, const ws_particle80 *host, bool reset_index)
-{
-    const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
-    ws_status st = ensure_stage(h, bytes);
-    if (st) return st;
-    HIP_TRY(h, hipMemcpyAsync(h->stage, host, bytes, hipMemcpyHostToDevice, h->stream));
-    wsk_ref_load(h->stream, (const ws_particle80 *)h->stage, h->ref, h->n, reset_index);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->steps = 0;
-    return WS_OK;
-}
-
-ws_status ref_upload_positions(ws_handle *h, const float *pos_xyz)
-{
-    std::vector<ws_particle80> rec(h->n);  // FluidParticle::make_vec_from_positions, fluid_compute.rs:118-130
-    memset(rec.data(), 0, rec.size() * sizeof(ws_particle80));
-    for (uint32_t i = 0; i < h->n; i++)
-        for (int c = 0; c < 3; c++) rec[i].position[c] = rec[i].predicted_position[c] = pos_xyz[3 * (size_t)i + c];
-    return ref_load(h, rec.data(), true);
-}
-
 // cur.pred is not maintained by the step loop (k_reorder recomputes it): bring it up to date for a reader off the loop
 void refresh_pred(ws_handle *h, const WsDev &d)
 {
@@ -390,7 +378,7 @@ void refresh_pred(ws_handle *h, const WsDev &d)
 // starts), storing nothing but accel[].  Not profiled: it is not part of a step.
 ws_status refresh_accel(ws_handle *h)
 {
-    if (!h->accel_stale || h->refmode) return WS_OK;
+    if (!h->accel_stale) return WS_OK;
     WsDev d = h->dev;
     if (h->slab) {
         d.dyn = h->slab->dyn;
@@ -456,8 +444,9 @@ void free_all(ws_handle *h)
     hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->mask.words); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
-    hipFree(h->ref.pos); hipFree(h->ref.vel); hipFree(h->ref.pred); hipFree(h->ref.acc); hipFree(h->ref.dens);
-    hipFree(h->ref.perm); hipFree(h->ref.keys); hipFree(h->ref.offs);
+#ifdef WS_WITH_REFCHECK
+    ref_free(h);
+#endif
     slab_free(h);
     if (h->done) hipEventDestroy(h->done);
     if (h->stream && h->own_stream) hipStreamDestroy(h->stream);
@@ -626,18 +615,14 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_HIP(hipEventCreateWithFlags(&h->done, hipEventDisableTiming));
     CREATE_TRY(derive_dev(h, *params, n, &h->dev));
+#ifdef WS_WITH_REFCHECK
     if (h->flags & WS_FLAG_REFERENCE_ORDER) {
-        h->refmode = true;
-        const size_t n16r = (size_t)n * 16;
-        CREATE_HIP(hipMalloc(&h->ref.pos, n16r)); CREATE_HIP(hipMalloc(&h->ref.vel, n16r));
-        CREATE_HIP(hipMalloc(&h->ref.pred, n16r)); CREATE_HIP(hipMalloc(&h->ref.acc, n16r));
-        CREATE_HIP(hipMalloc(&h->ref.dens, (size_t)n * 8));
-        CREATE_HIP(hipMalloc(&h->ref.perm, (size_t)n * 4)); CREATE_HIP(hipMalloc(&h->ref.keys, (size_t)n * 4));
-        CREATE_HIP(hipMalloc(&h->ref.offs, (size_t)n * 4));
+        CREATE_TRY(ref_alloc(h));
         CREATE_TRY(ref_upload_positions(h, pos_xyz));
         *out = h;
         return WS_OK;
     }
+#endif
     // +16 entries: phase 1 trips read up to U-1 slots past a run's end (masked, but must be mapped)
     const size_t n16 = ((size_t)n + 16) * 16;
     CREATE_HIP(hipMalloc(&h->cur.pos, n16));
@@ -689,14 +674,7 @@ ws_status ws_step(ws_handle *h)
     if (!h) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_step(h);
-    if (h->refmode) {
-        wsk_ref_step(h->stream, h->dev, h->ref);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipEventRecord(h->done, h->stream));
-        h->done_recorded = true;
-        h->steps++;
-        return WS_OK;
-    }
+    WS_REF_DISPATCH(h, ref_step(h));
     hipStream_t s = h->stream;
     // (A hipGraph replay of this fixed 7-launch sequence was measured and is NOT faster than the direct
     // launches, which already pipeline on the stream: C1 0.061 vs 0.055 ms/step, C2 0.107 vs 0.100, C3 equal.)
@@ -759,7 +737,7 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
         nd.has_left = od.has_left; nd.has_right = od.has_right; nd.mig = od.mig;
         memcpy(nd.lidx, od.lidx, sizeof nd.lidx);
     }
-    if (h->refmode) regrid = false;  // no cell grid in reference-order mode
+    WS_REF_DISPATCH(h, ref_set_params(h, params, nd));
     if (h->slab && regrid)
         return fail(h, WS_ERR_UNSUPPORTED, "a slab handle cannot re-grid (smoothing radius / container are fixed)");
     // The last step's accelerations are computed on demand from the state and the parameters that step used: if a
@@ -791,14 +769,7 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
     if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->refmode) {
-        std::vector<ws_particle80> rec(h->n);
-        const ws_status s_ = ws_read_particles(h, rec.data());
-        if (s_) return s_;
-        for (uint32_t i = 0; i < h->n; i++)
-            for (int c = 0; c < 3; c++) out_xyz[3 * (size_t)i + c] = rec[i].position[c];
-        return WS_OK;
-    }
+    WS_REF_DISPATCH(h, ref_read_positions(h, out_xyz));
     const size_t bytes = (size_t)h->n * 12;
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
@@ -816,7 +787,8 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
 {
     if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
-    if (h->slab || h->refmode) return fail(h, WS_ERR_UNSUPPORTED, "asynchronous readback needs a plain single-GPU handle");
+    WS_REF_DISPATCH(h, fail(h, WS_ERR_UNSUPPORTED, "no asynchronous readback in the reference-order validation mode"));
+    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "asynchronous readback needs a plain single-GPU handle");
     if (h->rb_inflight) return fail(h, WS_ERR_INVALID_ARG, "a readback is already in flight (call ws_read_positions_end)");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)h->n * 12;
@@ -857,16 +829,7 @@ ws_status ws_read_speeds(ws_handle *h, float *out_speed)
     if (!h || !out_speed) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->refmode) {
-        std::vector<ws_particle80> rec(h->n);
-        const ws_status s_ = ws_read_particles(h, rec.data());
-        if (s_) return s_;
-        for (uint32_t i = 0; i < h->n; i++) {
-            const float *v = rec[i].velocity;
-            out_speed[i] = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        }
-        return WS_OK;
-    }
+    WS_REF_DISPATCH(h, ref_read_speeds(h, out_speed));
     const size_t bytes = (size_t)h->n * 4;
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
@@ -903,16 +866,10 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
     if (!h || !out) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
+    WS_REF_DISPATCH(h, ref_read_particles(h, out));
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
-    if (h->refmode) {
-        wsk_ref_store(h->stream, h->dev, h->ref, (ws_particle80 *)h->stage, h->n);
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        return WS_OK;
-    }
     refresh_pred(h, h->dev);
     st = refresh_accel(h);
     if (st) return st;
@@ -929,7 +886,7 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz)
     if (!h || !pos_xyz) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->refmode) return ref_upload_positions(h, pos_xyz);
+    WS_REF_DISPATCH(h, ref_upload_positions(h, pos_xyz));
     return upload_positions(h, pos_xyz);
 }
 
@@ -938,7 +895,7 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
     if (!h || !in) return WS_ERR_INVALID_ARG;
     if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->refmode) return ref_load(h, in, false);  // write_slice("particles") leaves the index buffers alone
+    WS_REF_DISPATCH(h, ref_load(h, in, false));  // write_slice("particles") leaves the index buffers alone
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
@@ -964,13 +921,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     HIP_TRY(h, hipSetDevice(h->device));
     const uint32_t n = h->n;
     hipStream_t s = h->stream;
-    if (h->refmode) {  // the real buffers, permutation included
-        HIP_TRY(h, hipStreamSynchronize(s));
-        if (keys_by_id) HIP_TRY(h, hipMemcpy(keys_by_id, h->ref.keys, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if (perm) HIP_TRY(h, hipMemcpy(perm, h->ref.perm, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if (cell_offsets) HIP_TRY(h, hipMemcpy(cell_offsets, h->ref.offs, (size_t)n * 4, hipMemcpyDeviceToHost));
-        return WS_OK;
-    }
+    WS_REF_DISPATCH(h, ref_read_sort_view(h, keys_by_id, perm, cell_offsets));
     if (!h->v_keys) {
         HIP_TRY(h, hipMalloc(&h->v_keys, (size_t)n * 4));
         HIP_TRY(h, hipMalloc(&h->v_perm, (size_t)n * 4));

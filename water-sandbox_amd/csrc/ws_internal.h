@@ -96,14 +96,11 @@ struct WsSoA {
     uint32_t *rank;
 };
 
-// Reference-order mode (WS_FLAG_REFERENCE_ORDER): the reference's own buffer set, by particle id
-struct WsRef {
-    float4 *pos = nullptr, *vel = nullptr, *pred = nullptr, *acc = nullptr;  // w = 0
-    float2 *dens = nullptr;    // (density, near density)
-    uint32_t *perm = nullptr;  // particle_indicies
-    uint32_t *keys = nullptr;  // particle_cell_indicies (by particle id)
-    uint32_t *offs = nullptr;  // cell_offsets
-};
+// The test-only build (tests/libwsfluid_refcheck.so, -DWS_WITH_REFCHECK -Itests/refcheck) adds a validation mode
+// whose declarations, kernels and host code all live under tests/refcheck/; the product build sees none of it.
+#ifdef WS_WITH_REFCHECK
+#include "ws_refcheck.h"
+#endif
 
 // planar copy of the sorted predicted positions (K4's radius tests)
 // The cell-sorted copy.  Predicted position and velocity are interleaved: a neighbour's {pred.xyz, density}
@@ -193,8 +190,10 @@ struct ws_handle {
     double prof_ms[WS_K_COUNT] = {0};
     uint64_t prof_cnt[WS_K_COUNT] = {0};
 
-    bool refmode = false;  // WS_FLAG_REFERENCE_ORDER
+#ifdef WS_WITH_REFCHECK
+    bool refmode = false;  // WS_FLAG_REFERENCE_ORDER (test-only build)
     WsRef ref;
+#endif
 
     // slab (multi-GPU) state; slab == nullptr on a single-GPU handle
     bool accel_stale = false;  // accel[] is behind the last step (computed on demand: refresh_accel)
@@ -272,17 +271,6 @@ void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, cons
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
 void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
-// reference-order validation mode: compiled only into the test-only build (-DWS_WITH_REFCHECK, ws_refcheck.inc).
-// The product library refuses WS_FLAG_REFERENCE_ORDER in ws_create, so the stubs below are never reached.
-#ifdef WS_WITH_REFCHECK
-void wsk_ref_step(hipStream_t s, const WsDev &d, WsRef r);
-void wsk_ref_load(hipStream_t s, const ws_particle80 *in_dev, WsRef r, uint32_t n, bool reset_index);
-void wsk_ref_store(hipStream_t s, const WsDev &d, WsRef r, ws_particle80 *out_dev, uint32_t n);
-#else
-inline void wsk_ref_step(hipStream_t, const WsDev &, WsRef) {}
-inline void wsk_ref_load(hipStream_t, const ws_particle80 *, WsRef, uint32_t, bool) {}
-inline void wsk_ref_store(hipStream_t, const WsDev &, WsRef, ws_particle80 *, uint32_t) {}
-#endif
 // slabs
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cur, uint32_t *count);
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,

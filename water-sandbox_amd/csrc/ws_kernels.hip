@@ -1702,8 +1702,8 @@ void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_
 
 // ---------------------------------------------------------------------------------
 // The reference-order validation kernels (a literal HIP restatement of the six WGSL entry points, used only to
-// cross-check the CPU restatement bit for bit) are NOT part of the product library: they live in ws_refcheck.inc and are
-// compiled only into the test-only build (tests/libwsfluid_refcheck.so, -DWS_WITH_REFCHECK).
+// cross-check the CPU restatement bit for bit) are NOT part of the product: they live in tests/refcheck/ and are
+// compiled only into the test-only build (tests/libwsfluid_refcheck.so, -DWS_WITH_REFCHECK -Itests/refcheck).
 // ---------------------------------------------------------------------------------
 #ifdef WS_WITH_REFCHECK
 #include "ws_refcheck.inc"
