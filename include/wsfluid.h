@@ -211,8 +211,11 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  * ranges and the ghost counts stay on the device, kernels are launched over host-side upper bounds.  A capacity
  * overrun clamps, sets a sticky error bit that reaches every rank with the next step's all-gather, and makes ws_step
  * return WS_ERR_OUT_OF_MEMORY on ALL ranks at the same step (two steps later), before any collective of that step --
- * no rank is left waiting in one; ws_sync / ws_slab_read_particles report it too.  ws_num_particles of a slab is
- * exact after ws_sync.
+ * no rank is left waiting in one.  ws_sync / ws_slab_read_particles / ws_slab_counters report the bits too, as soon
+ * as this rank knows them -- which may be one or two steps before the other ranks do: such a report is information,
+ * not the signal to stop; keep calling ws_step until IT fails (it does on every rank at the same step, and until
+ * then it keeps issuing the step's collectives so that no peer waits alone).  ws_num_particles of a slab is exact
+ * after ws_sync.
  * All data movement goes through the two transport callbacks below (bench.py uses the library's own RCCL
  * transport, ws_rccl_transport_create; tests also drive them with torch.distributed and with an in-process
  * loopback).  The particle order inside a cell is canonical (by id), so an N-slab run reproduces the single-GPU
@@ -300,10 +303,16 @@ ws_status ws_profile_reset(ws_handle *h);
 /* Restrict WS_FLAG_PROFILE's events to the kernel ids whose bit is set in mask (default: all),
  * so that a timed region carries two events per step instead of two per kernel. */
 ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
-/* Cumulative device-side counters: out[0] = particle-steps with more candidates than the accept mask holds
- * (their waves took the full sweep in the force kernel); the rest reserved. */
+/* out[0] = cumulative particle-steps with more candidates than the accept mask holds (their waves took the full
+ * sweep in the force kernel); out[1..3] = how many of the reference's cells (edge = smoothing radius) one cell of the
+ * device grid spans along x, y, z -- 1 unless the reference-sized grid would exceed the cell budget (a small
+ * smoothing radius in a big container), see ws_grid_dims; the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
-/* Device cell grid actually in use (cells along x,y,z incl. padding). */
+/* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
+ * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when
+ * container volume / h^3 exceeds the cell budget (max(16 N, 2^24) cells) the library merges cells along z, then y,
+ * then x.  Results are unaffected (cell edges stay >= h; the distance test decides); no radius the reference accepts
+ * makes ws_create / ws_set_params run out of table memory. */
 ws_status ws_grid_dims(ws_handle *h, uint32_t dims[3]);
 
 #ifdef __cplusplus

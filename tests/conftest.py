@@ -57,6 +57,6 @@ def pytest_sessionfinish(session, exitstatus):
             json.dump({"policy": "tolerance = 4 x L-inf(oracle - oracle with reversed neighbour order) + 4 ulp x max|field| "
                                  "(8 x for the golden one-step tests); bitwise records have tolerance 0",
                        "comparisons": len(PARITY_REPORT), "worst_per_field_and_arithmetic": worst,
-                       "records": PARITY_REPORT}, f, indent=1)
+                       "records": PARITY_REPORT}, f, indent=1, default=float)
     except OSError:
         pass

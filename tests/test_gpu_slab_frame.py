@@ -1,0 +1,165 @@
+"""The host's whole per-frame boundary on slab (multi-GPU) handles, on ONE GPU through the loopback transport.
+
+The reference's host needs, every frame, id-ordered positions of ALL particles (update(), src/fluid_compute.rs:478-485),
+pushes parameters (:479-481; the HUD can change the smoothing radius, src/hud.rs:135-138, which changes the cell grid)
+and resets on Space (despawn_liquid, :505-525).  On slab handles these are collective calls over global, id-ordered
+arrays; the frame loop below -- written once against the worker interface -- must give bit-identical results on one
+handle and on 2 / 3 / 4 slabs, through a reset and two radius changes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame_loop(ws, pos, params, frames, events):
+    """update -> despawn -> run, in the order of src/schedule.rs:24-36.  events: {frame: ("reset",) | ("params", p)}."""
+
+    def program(w, rank=0):
+        seen = {}
+        current = params
+        for f in range(frames):
+            ev = events.get(f)
+            if ev and ev[0] == "reset":            # Update / DespawnEntities: despawn_liquid
+                w.reset(pos)
+            if ev and ev[0] == "params":           # Update / UserInput: the HUD edits FluidStaticProps / Gravity
+                current = ev[1]
+            xyz = w.read_positions()               # Update / EntityUpdates: update() reads the positions ...
+            w.set_params(current)                  # ... and pushes fluid_props / smoothing_kernel / gravity
+            if f % 5 == 0 or f == frames - 1:
+                seen[f] = xyz
+            w.run(1)                               # PostUpdate / Pass
+        return seen, w.read_vec("particles"), w.sort_view(), w.read_speeds()
+
+    return program
+
+
+def _events(ws, size):
+    return {
+        6: ("params", ws.make_params(container_size=size, gravity=(6.0, -9.8, 0.0, 0.0), smoothing_radius=0.35)),
+        14: ("reset",),
+        20: ("params", ws.make_params(container_size=size, gravity=(-4.0, -9.8, 1.0, 0.0), smoothing_radius=0.15,
+                                      viscosity_strength=0.2)),
+    }
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_frame_loop_with_reset_and_radius_changes_is_bit_identical_on_slabs(ws, world):
+    size = (16.0, 9.0, 9.0)
+    params = ws.make_params(container_size=size, gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(40000, 808, list(params.ext_min), list(params.ext_max))  # not a power of two
+    frames = 30
+    program = _frame_loop(ws, pos, params, frames, _events(ws, size))
+    single = ws.FluidWorker(pos, params)
+    want_seen, want_rec, want_view, want_speed = program(single)
+    single.close()
+    results = ws.slab.run_loopback_program(pos, params, world, program)
+    for r, (seen, rec, view, speed) in enumerate(results):   # every rank gets the whole, id-ordered arrays
+        for f in want_seen:
+            assert np.array_equal(seen[f].view(np.uint32), want_seen[f].view(np.uint32)), "positions of frame %d, rank %d" % (f, r)
+        for name in want_rec.dtype.names:
+            assert np.array_equal(rec[name].view(np.uint32), want_rec[name].view(np.uint32)), (name, r)
+        for a, b in zip(view, want_view):                    # particle_cell_indicies / particle_indicies / cell_offsets
+            assert np.array_equal(a, b)
+        assert np.array_equal(speed.view(np.uint32), want_speed.view(np.uint32))
+
+
+def test_slab_handles_take_and_return_global_records(ws):
+    """ws_write_particles / ws_read_particles on slab handles: every rank is handed ALL records (id order) and keeps
+    what its cuts own -- by PREDICTED position, which is what the step bins by --, and every rank reads ALL records
+    back.  Round trip without a step is the identity on position / velocity / predicted position; stepping from the
+    written state equals the single handle."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(32768, 31, list(params.ext_min), list(params.ext_max))
+    w = ws.FluidWorker(pos, params)
+    w.run(10)
+    state = w.read_vec("particles")
+    w.write_slice("particles", state)
+    w.run(5)
+    want = w.read_vec("particles")
+    w.close()
+
+    def program(s, rank):
+        s.write_particles(state)
+        back = s.read_vec("particles")
+        owned = s.num_owned()
+        s.run(5)
+        return back, s.read_vec("particles"), owned
+
+    results = ws.slab.run_loopback_program(pos, params, 3, program)
+    assert sum(r[2] for r in results) == pos.shape[0]
+    for back, got, _ in results:
+        for f in ("position", "velocity", "predicted_position"):
+            assert np.array_equal(back[f].view(np.uint32), state[f].view(np.uint32)), f
+        assert not back["density"].any() and not back["acceleration"].any()   # no step on this set yet
+        for f in want.dtype.names:
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_asynchronous_global_readback_on_slabs(ws):
+    """ws_read_positions_begin / _end on slab handles: the positions as of the steps enqueued before `begin`,
+    whatever is enqueued afterwards."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0))
+    pos = ws.workloads.uniform_cloud(20000, 4, list(params.ext_min), list(params.ext_max))
+
+    def program(s, rank):
+        s.run(3)
+        want = s.read_positions()
+        buf = np.empty((pos.shape[0], 3), np.float32)
+        s.read_positions_begin(buf)
+        s.run(4)
+        s.read_positions_end()
+        return want, buf, s.read_positions()
+
+    w = ws.FluidWorker(pos, params)
+    w.run(3)
+    single3 = w.read_positions()
+    w.run(4)
+    single7 = w.read_positions()
+    w.close()
+    for want, buf, later in ws.slab.run_loopback_program(pos, params, 2, program):
+        assert np.array_equal(want, single3) and np.array_equal(buf, single3) and np.array_equal(later, single7)
+
+
+def test_capacity_overrun_with_a_sync_after_every_step_still_fails_every_rank_at_the_same_step(ws):
+    """The frame pattern is step-then-read: a rank that learns of ITS overrun in ws_sync (one or two steps before the
+    others can) must keep stepping -- and issuing the step's collectives -- until ws_step itself fails, on every rank at
+    the same step.  (ws_sync used to latch the local bit and the rank then left its peers alone in the next collective.)"""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
+    world = 3
+    errs = ws.slab.run_loopback(pos, params, world, 80, collect_errors=True, sync_every_step=True,
+                                capacity=65536 // world + 256)
+    step_errs = {k: v for k, v in errs.items() if not isinstance(k, tuple)}
+    assert sorted(step_errs) == list(range(world)), "every rank must fail in ws_step: %r" % (errs,)
+    assert len({k for k, _ in step_errs.values()}) == 1, "all ranks must fail at the same step: %r" % (errs,)
+    early = [k for k in errs if isinstance(k, tuple)]
+    assert early, "some rank should have heard of the overrun from ws_sync before ws_step failed"
+    for k, e in step_errs.values():
+        assert e.status == 3 and "capacity" in str(e), e
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_particles_that_overshoot_the_padding_with_halo_overlap_on(ws, monkeypatch, world):
+    """Predicted positions that leave the two cells of padding are clamped into the grid's border rows, whose
+    linearised stencil wraps into the neighbouring LAYER -- for the first / last early layer of a slab a ghost layer,
+    whose cell starts the halo stream is rewriting while the early range computes.  Early launches cut their runs to
+    the owned range, so K4 and K5 number their candidates alike whatever the ghost starts hold: bit-identical to the
+    single handle."""
+    monkeypatch.setenv("WS_SLAB_OVERLAP", "1")
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0))
+    pos = ws.workloads.uniform_cloud(65536, 77, list(params.ext_min), list(params.ext_max))
+    orc_like = np.zeros(pos.shape[0], ws.PARTICLE_DTYPE)
+    orc_like["position"][:, :3] = pos
+    rng = np.random.default_rng(3)
+    fast = rng.choice(pos.shape[0], 6000, replace=False)   # v / 50 far beyond the 0.5 units of padding, every direction in y, z
+    orc_like["velocity"][fast, 1:3] = rng.choice([-300.0, 300.0], (fast.size, 2)).astype(np.float32)
+    orc_like["predicted_position"][:, :3] = orc_like["position"][:, :3] + orc_like["velocity"][:, :3] * np.float32(0.02)
+    w = ws.FluidWorker(pos, params)
+    w.write_slice("particles", orc_like)
+    w.run(6)
+    want = w.read_vec("particles")
+    w.close()
+    got, owned = ws.slab.run_loopback(pos, params, world, 6, state=orc_like)
+    assert sum(owned) == pos.shape[0]
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f

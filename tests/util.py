@@ -53,7 +53,7 @@ def reorder_noise_tolerances(a, b, scale=4.0):
     for f in FLOAT_FIELDS:
         noise = _linf(a[f], b[f])
         mag = float(np.max(np.abs(a[f])))
-        tol[f] = scale * noise + 4.0 * np.finfo(np.float32).eps * max(mag, 1e-30)
+        tol[f] = float(scale * noise + 4.0 * float(np.finfo(np.float32).eps) * max(mag, 1e-30))
         noise_of[f] = noise
     tol["_noise"] = noise_of
     return tol
@@ -65,7 +65,7 @@ def assert_particles_close(got, want, tol, what="", arithmetic=None):
     for f in FLOAT_FIELDS:
         err = _linf(got[f], want[f])
         PARITY_REPORT.append({"case": what, "arithmetic": arithmetic, "field": f, "n": int(len(got)), "linf_error": err,
-                              "noise_unit": noise.get(f), "tolerance": tol[f],
+                              "noise_unit": noise.get(f), "tolerance": float(tol[f]),
                               "error_over_tolerance": err / tol[f] if tol[f] > 0 else (0.0 if err == 0 else float("inf"))})
         if not err <= tol[f]:
             failures.append("%s field %s: L-inf error %.3e > tolerance %.3e" % (what, f, err, tol[f]))

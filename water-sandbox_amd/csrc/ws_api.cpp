@@ -15,13 +15,19 @@
 namespace {
 
 constexpr int kGridPad = 2;                     // empty cell layers around the container
-constexpr uint64_t kMaxCells = 1ull << 29;      // 3 x u32 per cell -> 6 GiB of tables
+constexpr uint64_t kMaxCells = 1ull << 29;      // hard cap of the cell tables (3 x u32 per cell -> 6 GiB); see derive_dev
 
 thread_local std::string g_create_error;
 
-void slab_free(ws_handle *h);          // ws_slab.inc
-ws_status slab_step(ws_handle *h);     // ws_slab.inc
-ws_status slab_settle(ws_handle *h);   // ws_slab.inc
+// ws_slab.inc
+void slab_free(ws_handle *h);
+ws_status slab_step(ws_handle *h);
+ws_status slab_settle(ws_handle *h);
+ws_status slab_read_by_id(ws_handle *h, int kind, void *out);
+ws_status slab_gather_by_id(ws_handle *h, int kind);
+ws_status slab_reset(ws_handle *h, const float *pos_xyz);
+ws_status slab_write_particles(ws_handle *h, const ws_particle80 *in);
+ws_status slab_regrid(ws_handle *h, const ws_params *params);
 
 ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
 {
@@ -118,18 +124,42 @@ ws_status derive_dev(ws_handle *h, const ws_params &p, uint32_t n, WsDev *out)
         d.ext_max[c] = p.ext_max[c];
     }
     d.d2_accept = accept_threshold(d.h);
+    // Reference-sized cells (edge h) over the container padded by kGridPad cells.  Cell coordinates are carried as
+    // f32 in the kernels (floorf(x / h) - org): keep them exactly representable.
     uint64_t cells = 1;
     for (int c = 0; c < 3; c++) {
         const double lo = floor((double)floorf(p.ext_min[c] / d.h)) - kGridPad;
         const double hi = floor((double)floorf(p.ext_max[c] / d.h)) + kGridPad;
         const double dim = hi - lo + 1.0;
-        if (!(fabs(lo) < 1e9) || !(dim < 1e9)) return fail(h, WS_ERR_INVALID_ARG, "container / smoothing_radius out of range");
+        if (!(fabs(lo) < 8388608.0) || !(fabs(hi) < 8388608.0))
+            return fail(h, WS_ERR_INVALID_ARG, "container / smoothing_radius out of range (more than 2^23 cells along an axis)");
         d.org[c] = (int32_t)lo;
-        d.dim[c] = (int32_t)dim;
-        cells *= (uint64_t)d.dim[c];
-        if (cells > kMaxCells)
-            return fail(h, WS_ERR_OUT_OF_MEMORY, "cell grid too large (container volume / smoothing_radius^3 > 2^29)");
+        d.fdim[c] = d.dim[c] = (int32_t)dim;
+        d.cm[c] = 1;
+        cells *= (uint64_t)d.dim[c];  // < 2^69 / overflow-free: three factors below 2^24
     }
+    // The cell budget.  The reference's N-bucket hashed table (simulation.wgsl:125-128) costs the same whatever the
+    // smoothing radius; a dense grid of reference-sized cells does not (two HUD key presses take h from 0.25 to 0.05,
+    // src/hud.rs:135-138: 125 x the cells).  When the reference-sized grid exceeds the budget, grid cells are MERGED
+    // along z first (a (dx, dy) column stays one contiguous particle run, only longer), then y, then x, until it
+    // fits: every cell edge stays >= h, so the 27-cell search still sees every neighbour, the order inside the
+    // runs stays canonical (multi-GPU bit-identity), and the only cost is more candidates for the distance test.
+    // No smoothing radius the reference accepts runs out of table memory.
+    uint64_t budget = std::max<uint64_t>(16ull * n, 1ull << 24);
+    if (const char *v = getenv("WS_CELL_BUDGET")) budget = std::max<uint64_t>(strtoull(v, nullptr, 10), 64);  // experiments
+    budget = std::min<uint64_t>(budget, kMaxCells);
+    for (int c = 2; c >= 0 && cells > budget; c--) {
+        const uint64_t others = cells / (uint64_t)d.dim[c];
+        // smallest merge factor that brings this axis (and with it the grid) under the budget, at most the whole axis
+        uint64_t want = std::max<uint64_t>(budget / std::max<uint64_t>(others, 1), 1);  // grid cells this axis may keep
+        uint64_t m = ((uint64_t)d.fdim[c] + want - 1) / want;
+        m = std::min<uint64_t>(std::max<uint64_t>(m, 1), (uint64_t)d.fdim[c]);
+        d.cm[c] = (int32_t)m;
+        d.dim[c] = (int32_t)(((uint64_t)d.fdim[c] + m - 1) / m);
+        cells = others * (uint64_t)d.dim[c];
+    }
+    d.coarse = (d.cm[0] != 1 || d.cm[1] != 1 || d.cm[2] != 1) ? 1u : 0u;
+    if (cells > kMaxCells) return fail(h, WS_ERR_OUT_OF_MEMORY, "cell grid too large even with merged cells");
     d.ncells = (uint32_t)cells;
     d.guard = d.dim[1] * d.dim[2] + d.dim[2] + 1;
     d.n = n;
@@ -294,15 +324,18 @@ struct Prof {
 };
 
 // The same for ONE kernel launch: the pair goes to the launch (hipExtLaunchKernelGGL start / stop events) instead of
-// being recorded around it.
+// being recorded around it.  The pair is queued for reading only if a launch actually took it (events()); otherwise
+// it goes back to the pool -- a pair no launch has stamped would read as the elapsed time of an earlier use.
 struct ProfLaunch {
     ws_handle *h;
-    bool on;
+    bool on, taken = false;
     WsEventPair p{};
-    ProfLaunch(ws_handle *h_, uint32_t k) : h(h_), on((h_->flags & WS_FLAG_PROFILE) != 0 && ((h_->prof_mask >> k) & 1u))
+    ProfLaunch(ws_handle *h_, uint32_t k, bool counts = true)
+        : h(h_), on((h_->flags & WS_FLAG_PROFILE) != 0 && ((h_->prof_mask >> k) & 1u))
     {
         if (!on) return;
         p.kernel = k;
+        p.counts = counts;
         p.a = get_event(h);
         p.b = get_event(h);
         if (!p.a || !p.b) {
@@ -311,10 +344,22 @@ struct ProfLaunch {
             on = false;
         }
     }
-    const WsEventPair *events() const { return on ? &p : nullptr; }
+    // called by the launcher at the moment it launches
+    const WsEventPair *events()
+    {
+        if (!on) return nullptr;
+        taken = true;
+        return &p;
+    }
     ~ProfLaunch()
     {
-        if (on) h->pending.push_back(p);
+        if (!on) return;
+        if (taken) {
+            h->pending.push_back(p);
+        } else {
+            h->pool.push_back(p.a);
+            h->pool.push_back(p.b);
+        }
     }
 };
 
@@ -324,12 +369,20 @@ void drain_profile(ws_handle *h)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             h->prof_ms[p.kernel] += ms;
-            h->prof_cnt[p.kernel] += 1;
+            h->prof_cnt[p.kernel] += p.counts ? 1 : 0;
         }
         h->pool.push_back(p.a);
         h->pool.push_back(p.b);
     }
     h->pending.clear();
+}
+
+// WS_FLAG_PROFILE with a host that never calls ws_sync: read the event pairs back before the list (and the event
+// pool behind it) grows without bound.  Profile mode only; costs one stream synchronisation per 4096 pairs.
+void bound_pending(ws_handle *h)
+{
+    if (h->pending.size() < 4096) return;
+    if (hipStreamSynchronize(h->stream) == hipSuccess) drain_profile(h);
 }
 
 // The single-GPU step: scan -> scatter -> reorder -> K4 -> K5+K6+K1'.  Enqueued directly or captured.
@@ -424,6 +477,21 @@ ws_status upload_positions(ws_handle *h, const float *pos_xyz)
     return WS_OK;
 }
 
+void free_particle_arrays(ws_handle *h)
+{
+    hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred); hipFree(h->cur.rank);
+    hipFree(h->srt.pos); hipFree(h->srt.pv);
+    hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
+    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
+    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->mask.words);
+    h->cur = WsSoA{};
+    h->srt = WsSorted{};
+    h->sxyz = WsXYZ{};
+    h->cid_cur = h->cid_srt = h->slot_tmp = h->id_tmp = nullptr;
+    h->accel = nullptr;
+    h->mask = WsMask{nullptr, 0};
+}
+
 void free_all(ws_handle *h)
 {
     if (h->stream) hipStreamSynchronize(h->stream);
@@ -437,11 +505,8 @@ void free_all(ws_handle *h)
     drain_profile(h);
     for (auto e : h->pool) hipEventDestroy(e);
     free_grid(h);
-    hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred); hipFree(h->cur.rank);
-    hipFree(h->srt.pos); hipFree(h->srt.pv);
-    hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
-    hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->mask.words); hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
+    free_particle_arrays(h);
+    hipFree(h->stats); hipFree(h->mult); hipFree(h->stage);
     hipFree(h->v_keys); hipFree(h->v_perm); hipFree(h->v_tmp); hipFree(h->v_count);
     hipFree(h->v_cursor); hipFree(h->v_start); hipFree(h->v_bsum); hipFree(h->v_off);
 #ifdef WS_WITH_REFCHECK
@@ -678,6 +743,7 @@ ws_status ws_step(ws_handle *h)
     hipStream_t s = h->stream;
     // (A hipGraph replay of this fixed 7-launch sequence was measured and is NOT faster than the direct
     // launches, which already pipeline on the stream: C1 0.061 vs 0.055 ms/step, C2 0.107 vs 0.100, C3 equal.)
+    bound_pending(h);
     enqueue_step(h);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));
@@ -738,8 +804,8 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
         memcpy(nd.lidx, od.lidx, sizeof nd.lidx);
     }
     WS_REF_DISPATCH(h, ref_set_params(h, params, nd));
-    if (h->slab && regrid)
-        return fail(h, WS_ERR_UNSUPPORTED, "a slab handle cannot re-grid (smoothing radius / container are fixed)");
+    // (slab handles: COLLECTIVE when the cell size or the container changes -- every rank must make the same call)
+    if (h->slab && regrid) return slab_regrid(h, params);
     // The last step's accelerations are computed on demand from the state and the parameters that step used: if a
     // parameter they depend on changes (or the grid goes away), compute them now.  (A host that pushes unchanged
     // parameters every frame, as the reference's update() does, pays nothing.)
@@ -766,9 +832,9 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
 
 ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 {
-    if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
+    if (!h || (!out_xyz && !h->slab)) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) return slab_read_by_id(h, WS_PACK_POS_H, out_xyz);  // collective: all n_global positions, by id
     WS_REF_DISPATCH(h, ref_read_positions(h, out_xyz));
     const size_t bytes = (size_t)h->n * 12;
     ws_status st = ensure_stage(h, bytes);
@@ -788,27 +854,36 @@ ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
 {
     if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
     WS_REF_DISPATCH(h, fail(h, WS_ERR_UNSUPPORTED, "no asynchronous readback in the reference-order validation mode"));
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "asynchronous readback needs a plain single-GPU handle");
     if (h->rb_inflight) return fail(h, WS_ERR_INVALID_ARG, "a readback is already in flight (call ws_read_positions_end)");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)h->n * 12;
+    const size_t bytes = (size_t)(h->slab ? h->slab->n_global : h->n) * 12;
     if (!h->copy_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
         HIP_TRY(h, hipEventCreateWithFlags(&h->rb_gathered, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->rb_done, hipEventDisableTiming));
     }
-    if (h->rb_bytes < bytes) {
-        hipFree(h->rb_stage);
-        h->rb_stage = nullptr;
-        h->rb_bytes = 0;
-        HIP_TRY(h, hipMalloc(&h->rb_stage, bytes));
-        h->rb_bytes = bytes;
+    const float *src;
+    if (h->slab) {
+        // the collective gather (it settles the enqueued steps: the counts travel through the host), then the copy of
+        // the id-ordered result overlaps with the steps enqueued after this call, as on a single handle
+        const ws_status st = slab_gather_by_id(h, WS_PACK_POS_H);
+        if (st) return st;
+        src = reinterpret_cast<const float *>(h->slab->g_out);
+    } else {
+        if (h->rb_bytes < bytes) {
+            hipFree(h->rb_stage);
+            h->rb_stage = nullptr;
+            h->rb_bytes = 0;
+            HIP_TRY(h, hipMalloc(&h->rb_stage, bytes));
+            h->rb_bytes = bytes;
+        }
+        wsk_gather_positions(h->stream, h->cur.pos, h->rb_stage, h->n);
+        HIP_TRY(h, hipGetLastError());
+        src = h->rb_stage;
     }
-    wsk_gather_positions(h->stream, h->cur.pos, h->rb_stage, h->n);
-    HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->rb_gathered, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->rb_gathered, 0));
-    HIP_TRY(h, hipMemcpyAsync(out_xyz, h->rb_stage, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(h, hipMemcpyAsync(out_xyz, src, bytes, hipMemcpyDeviceToHost, h->copy_stream));
     HIP_TRY(h, hipEventRecord(h->rb_done, h->copy_stream));
     h->rb_inflight = true;
     return WS_OK;
@@ -826,9 +901,9 @@ ws_status ws_read_positions_end(ws_handle *h)
 
 ws_status ws_read_speeds(ws_handle *h, float *out_speed)
 {
-    if (!h || !out_speed) return WS_ERR_INVALID_ARG;
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
+    if (!h || (!out_speed && !h->slab)) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) return slab_read_by_id(h, WS_PACK_SPEED_H, out_speed);
     WS_REF_DISPATCH(h, ref_read_speeds(h, out_speed));
     const size_t bytes = (size_t)h->n * 4;
     ws_status st = ensure_stage(h, bytes);
@@ -863,9 +938,9 @@ ws_status ws_unpin_host_buffer(ws_handle *h, void *ptr)
 
 ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
 {
-    if (!h || !out) return WS_ERR_INVALID_ARG;
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
+    if (!h || (!out && !h->slab)) return WS_ERR_INVALID_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) return slab_read_by_id(h, WS_PACK_RECORD_H, out);  // collective: all n_global records, by id
     WS_REF_DISPATCH(h, ref_read_particles(h, out));
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
@@ -884,8 +959,8 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
 ws_status ws_reset(ws_handle *h, const float *pos_xyz)
 {
     if (!h || !pos_xyz) return WS_ERR_INVALID_ARG;
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) return slab_reset(h, pos_xyz);  // pos_xyz: ALL n_global positions, on every rank
     WS_REF_DISPATCH(h, ref_upload_positions(h, pos_xyz));
     return upload_positions(h, pos_xyz);
 }
@@ -893,8 +968,8 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz)
 ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
 {
     if (!h || !in) return WS_ERR_INVALID_ARG;
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) return slab_write_particles(h, in);  // in: ALL n_global records, on every rank
     WS_REF_DISPATCH(h, ref_load(h, in, false));  // write_slice("particles") leaves the index buffers alone
     const size_t bytes = (size_t)h->n * sizeof(ws_particle80);
     ws_status st = ensure_stage(h, bytes);
@@ -917,9 +992,10 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
 ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, uint32_t *cell_offsets)
 {
     if (!h) return WS_ERR_INVALID_ARG;
-    if (h->slab) return fail(h, WS_ERR_UNSUPPORTED, "not available on a slab handle (use ws_slab_read_particles)");
     HIP_TRY(h, hipSetDevice(h->device));
-    const uint32_t n = h->n;
+    // a slab handle answers for the WHOLE domain (collective: the keys of every rank's particles are gathered by id)
+    const uint32_t n = h->slab ? h->slab->n_global : h->n;
+    const bool stepped = h->slab ? h->steps > h->slab->t0 : h->steps > 0;
     hipStream_t s = h->stream;
     WS_REF_DISPATCH(h, ref_read_sort_view(h, keys_by_id, perm, cell_offsets));
     if (!h->v_keys) {
@@ -934,8 +1010,9 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         HIP_TRY(h, hipMemsetAsync(h->v_bsum, 0, (size_t)wsk_scan_state_words(n) * 4, h->stream));
         HIP_TRY(h, hipMemcpy(h->v_start + n, &n, 4, hipMemcpyHostToDevice));
     }
-    if (h->steps == 0) {
+    if (!stepped) {
         // src/fluid_compute.rs:306-308: all three buffers start as the identity
+        if (h->slab) HIP_TRY(h, hipStreamSynchronize(s));
         wsk_iota(s, h->v_keys, n);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -944,15 +1021,23 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         return WS_OK;
     }
     HIP_TRY(h, hipMemsetAsync(h->v_count, 0, (size_t)n * 4, s));
-    // the predicted positions the last step started from live in the sorted copy
-    wsk_view_keys(s, h->dev, h->srt, h->v_keys, h->v_count);
+    const uint32_t *keys = h->v_keys;
+    if (h->slab) {
+        const ws_status st = slab_gather_by_id(h, WS_PACK_KEY_H);
+        if (st) return st;
+        keys = h->slab->g_out;
+        wsk_view_count(s, keys, h->v_count, n);
+    } else {
+        // the predicted positions the last step started from live in the sorted copy
+        wsk_view_keys(s, h->dev, h->srt, h->v_keys, h->v_count);
+    }
     wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, &h->v_scan_launches, n, false, 0);
-    wsk_scatter(s, h->v_keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n, nullptr);
-    wsk_view_fix(s, h->v_tmp, h->v_keys, h->v_start, h->v_perm, n);
+    wsk_scatter(s, keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n, nullptr);
+    wsk_view_fix(s, h->v_tmp, keys, h->v_start, h->v_perm, n);
     wsk_view_offsets(s, h->v_start, h->v_off, n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
-    if (keys_by_id) HIP_TRY(h, hipMemcpy(keys_by_id, h->v_keys, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (keys_by_id) HIP_TRY(h, hipMemcpy(keys_by_id, keys, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (perm) HIP_TRY(h, hipMemcpy(perm, h->v_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (cell_offsets) HIP_TRY(h, hipMemcpy(cell_offsets, h->v_off, (size_t)n * 4, hipMemcpyDeviceToHost));
     return WS_OK;
@@ -996,6 +1081,7 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
     ws_status st = ws_sync(h);
     if (st) return st;
     HIP_TRY(h, hipMemcpy(out, h->stats, 64, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; c++) out[1 + c] = (uint32_t)h->dev.cm[c];  // reference cells merged per grid cell (host-side)
     return WS_OK;
 }
 

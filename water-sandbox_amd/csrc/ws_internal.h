@@ -36,7 +36,13 @@ struct WsDev {
     float d2_accept;
     // dense cell grid over the padded container: cell = floor(pred / h) (simulation.wgsl:121-123)
     int32_t org[3];  // grid origin in cell coordinates
-    int32_t dim[3];  // cells along x, y, z (z fastest in memory, x slowest)
+    int32_t dim[3];  // grid cells along x, y, z (z fastest in memory, x slowest)
+    // A grid cell is cm[c] of the reference's cells wide along axis c (1 everywhere unless the reference-sized grid
+    // would not fit the cell budget: a small smoothing radius in a big container, ws_api.cpp derive_dev).  Edges stay
+    // >= h, so the 27-cell search still covers every neighbour; candidates a wider cell adds fail the distance test.
+    int32_t fdim[3];  // reference-sized cells along x, y, z of the GLOBAL grid (== dim when cm == 1 on one GPU)
+    int32_t cm[3];
+    uint32_t coarse;  // any cm != 1
     int32_t guard;   // guard entries in front of / behind cell_start
     uint32_t n;      // particles the kernels process: sorted indices [base, base + n)
     uint32_t base;   // first owned slot of the sorted arrays (0 on one GPU; ghosts sit in front of it in a slab)
@@ -133,6 +139,7 @@ struct WsXYZ {
 struct WsEventPair {
     uint32_t kernel;
     hipEvent_t a, b;
+    bool counts = true;  // false: the second launch of a kernel id within one step (time is added, the launch count is per step)
 };
 
 struct ws_handle {
@@ -229,6 +236,15 @@ struct WsSlab {
     hipEvent_t ev_status[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t n_known = 0;             // owned count as of step n_known_step
     uint64_t n_known_step = 0;
+    uint64_t t0 = 0;                  // h->steps when the owned set was last loaded (create / reset / write / re-grid):
+                                      // status tables of earlier steps describe another particle set
+    uint32_t cfg_ghost_capacity = 0;  // ws_device_cfg.ghost_capacity as given (0 = derive from the grid)
+    // id-ordered global views (ws_read_positions & co. on a slab handle): count words, packed records of this rank,
+    // every rank's records, the id-ordered result
+    uint32_t *cnt_send = nullptr, *cnt_all = nullptr;
+    uint32_t *g_send = nullptr, *g_all = nullptr, *g_out = nullptr;
+    size_t g_send_bytes = 0, g_all_bytes = 0, g_out_bytes = 0;
+    std::vector<uint32_t> counts;     // owned particles per rank as of the last gather
     uint32_t failed = 0;              // sticky WS_DYN_ERR_* bits seen on any rank
     bool comm_failed = false;         // a transport call failed: the handle is dead
     // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute
@@ -267,6 +283,7 @@ void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt
                           ws_particle80 *out, uint32_t n);
 // reference-layout view
 void wsk_view_keys(hipStream_t s, const WsDev &d, WsSorted srt, uint32_t *keys_by_id, uint32_t *count);
+void wsk_view_count(hipStream_t s, const uint32_t *keys, uint32_t *count, uint32_t n);
 void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, const uint32_t *start,
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
@@ -285,3 +302,13 @@ void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted sr
 void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids);
 void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);
+// id-ordered global views / loads of slab handles (ws_kernels.hip "slab handles: the id-ordered GLOBAL views")
+enum { WS_PACK_POS_H = 0, WS_PACK_SPEED_H = 1, WS_PACK_RECORD_H = 2, WS_PACK_STATE_H = 3, WS_PACK_KEY_H = 4 };
+uint32_t wsk_pack_words(int kind);  // payload words per record (the record carries one more: the particle id)
+void wsk_slab_pack(hipStream_t s, const WsDev &d, int kind, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
+                   uint32_t *out);
+void wsk_slab_unpack_by_id(hipStream_t s, const uint32_t *all, const uint32_t *cnt, uint32_t world, uint32_t max_n,
+                           size_t stride_words, uint32_t pw, uint32_t n_global, uint32_t *out);
+void wsk_slab_select(hipStream_t s, const WsDev &d, int src, const uint32_t *cuts, uint32_t world, uint32_t me,
+                     const void *chunk, uint32_t id0, uint32_t m, const uint32_t *cnt, size_t stride_words, WsSoA cur,
+                     uint32_t cap, uint32_t *dyn);

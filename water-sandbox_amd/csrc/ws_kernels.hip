@@ -41,18 +41,29 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // Clamping is monotone per axis, so two particles whose true cells are adjacent stay
 // in adjacent-or-equal grid cells: the 27-cell search over grid cells visits a superset
 // of the reference's candidates and the exact distance test decides, as it does there.
-__device__ __forceinline__ uint32_t grid_cell(const WsDev &d, float x, float y, float z)
+// Global x layer (grid cells along x of the whole domain) of a position: the slab cuts are expressed in these.
+__device__ __forceinline__ int grid_layer_x(const WsDev &d, float x)
 {
     const float fx = floorf(x / d.h) - (float)d.org[0];
+    int gxg = (int)fminf(fmaxf(fx, 0.0f), (float)(d.fdim[0] - 1));  // fmaxf/fminf also squash NaN to the low border
+    if (d.coarse) gxg /= d.cm[0];
+    return gxg;
+}
+
+__device__ __forceinline__ uint32_t grid_cell(const WsDev &d, float x, float y, float z)
+{
     const float fy = floorf(y / d.h) - (float)d.org[1];
     const float fz = floorf(z / d.h) - (float)d.org[2];
-    // fmaxf/fminf also squash NaN to the low border
     // x: clamped in GLOBAL grid coordinates, then shifted into this handle's local (slab) grid and
     // clamped again so a particle that left the slab still bins inside the local tables
-    const int gxg = (int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
+    const int gxg = grid_layer_x(d, x);
+    int gy = (int)fminf(fmaxf(fy, 0.0f), (float)(d.fdim[1] - 1));
+    int gz = (int)fminf(fmaxf(fz, 0.0f), (float)(d.fdim[2] - 1));
+    if (d.coarse) {  // (wave-uniform; integer division only on the rare handles whose grid cells are merged)
+        gy /= d.cm[1];
+        gz /= d.cm[2];
+    }
     const int gx = min(max(gxg - d.xoff, 0), d.dim[0] - 1);
-    const int gy = (int)fminf(fmaxf(fy, 0.0f), (float)(d.dim[1] - 1));
-    const int gz = (int)fminf(fmaxf(fz, 0.0f), (float)(d.dim[2] - 1));
     return (uint32_t)((gx * d.dim[1] + gy) * d.dim[2] + gz);
 }
 
@@ -104,6 +115,37 @@ __device__ __forceinline__ WsSpan ws_span(const WsDev &d, const uint32_t *__rest
     return sp;
 }
 __device__ __forceinline__ uint32_t span_at(const WsSpan &sp, uint32_t v) { return sp.lo + v + (v >= sp.split ? sp.jump : 0u); }
+
+// The EARLY launches of a slab step (the particles whose searches touch no ghost layer) run while the halo exchange
+// on the other stream is still rewriting the ghost layers' cell starts (k_halo_unpack).  No true neighbour of an
+// early particle lies in a ghost layer -- but the linearised stencil of a particle clamped into a border row of the
+// grid (y row 0 or dim1 - 1, z column 0 or dim2 - 1: predicted positions that overshot the two cells of padding)
+// wraps around into the previous / next layer's cells, which for the first / last early layer is a ghost layer.
+// Those wrapped cells hold no neighbour (they are a whole grid extent away), but their run lengths number the
+// candidates of the accept masks: K4 (before the unpack) and K5 (after it) must count the same.  So early launches
+// cut every run to the owned range [base, base + n): a ghost layer's starts clamp to the same ends whatever they
+// hold.  Wave-uniform, nothing on a single-GPU handle.
+struct WsCut {
+    uint32_t lo, hi;
+    bool on;
+};
+__device__ __forceinline__ WsCut ws_cut(const WsDev &d)
+{
+    WsCut c = {0u, 0xFFFFFFFFu, false};
+    if (d.dyn && d.range_sel == WS_RANGE_EARLY) {
+        c.lo = d.base;
+        c.hi = d.base + d.dyn[DY_N];
+        c.on = true;
+    }
+    return c;
+}
+__device__ __forceinline__ void cut_run(const WsCut &c, uint32_t &b, uint32_t &e)
+{
+    if (c.on) {
+        b = min(max(b, c.lo), c.hi);
+        e = min(max(e, c.lo), c.hi);
+    }
+}
 
 // ---------------------------------------------------------------------------------
 // uploads
@@ -659,8 +701,7 @@ __device__ __forceinline__ void density_store(float density, float near_density,
 // everywhere here: the sort is canonical.
 __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint32_t i, float4 pos, float4 vel, float4 pred)
 {
-    const float fx = floorf(pred.x / d.h) - (float)d.org[0];
-    const uint32_t gxg = (uint32_t)(int)fminf(fmaxf(fx, 0.0f), (float)(d.gdim_x - 1));
+    const uint32_t gxg = (uint32_t)grid_layer_x(d, pred.x);
     uint32_t dest = 0;
     while (dest + 1 < m.world && gxg >= m.cuts[dest + 1]) dest++;
     const uint32_t hs = atomicAdd(&m.dyn[DY_NHOLE], 1u);
@@ -748,10 +789,12 @@ __device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint3
                                                      float &near_density)
 {
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    const WsCut cut = ws_cut(d);
     for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
-            const uint32_t b = start[cc - 1], e = start[cc + 2];
+            uint32_t b = start[cc - 1], e = start[cc + 2];
+            cut_run(cut, b, e);
             for (uint32_t j = b; j < e; j++) {
                 const float4 q = srt.pred(j);
                 const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
@@ -769,10 +812,12 @@ __device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_
                                                    float pressure, float near_pressure, ForceAcc &acc)
 {
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+    const WsCut cut = ws_cut(d);
     for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
-            const uint32_t b = start[cc - 1], e = start[cc + 2];
+            uint32_t b = start[cc - 1], e = start[cc + 2];
+            cut_run(cut, b, e);
             for (uint32_t j = b; j < e; j++) {
                 if (j == i) continue;  // `particle_index == neighbour_index`, simulation.wgsl:232
                 const float4 q = srt.pred(j);
@@ -993,6 +1038,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         }
     };
     uint32_t cnt = 0;
+    const WsCut cut = ws_cut(d);
     for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
         const int cc = d.guard + c + (p - 1) * rowy;
         // unconditional (iv is always a real particle), so the six loads go out together
@@ -1000,6 +1046,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         run_bounds(start, cc - rowz, b0, e0);
         run_bounds(start, cc, b1, e1);
         run_bounds(start, cc + rowz, b2, e2);
+        cut_run(cut, b0, e0);
+        cut_run(cut, b1, e1);
+        cut_run(cut, b2, e2);
         if (!valid) {
             e0 = b0;
             e1 = b1;
@@ -1049,6 +1098,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     {
         // unconditional loads (iv is always a real particle), six in flight per plane
         const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
+        const WsCut cut = ws_cut(d);
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             uint32_t b[3], e[3];
@@ -1057,6 +1107,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
                 const int cc = d.guard + c + (p - 1) * rowy + (q - 1) * rowz;
                 b[q] = start[cc - 1];  // (one 16-B load for both, as in K4: -4 % sparse, +4.5 % dense here)
                 e[q] = start[cc + 2];
+                cut_run(cut, b[q], e[q]);
             }
 #pragma unroll
             for (int q = 0; q < 3; q++) {
@@ -1322,6 +1373,18 @@ __global__ void __launch_bounds__(WS_BLOCK) k_view_keys(WsDev d, WsSorted srt,
 void wsk_view_keys(hipStream_t s, const WsDev &d, WsSorted srt, uint32_t *keys_by_id, uint32_t *count)
 {
     hipLaunchKernelGGL(k_view_keys, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, srt, keys_by_id, count);
+}
+
+// the histogram alone, for keys that are already there (slab handles: gathered by id)
+__global__ void __launch_bounds__(WS_BLOCK) k_view_count(const uint32_t *__restrict__ keys, uint32_t *__restrict__ count, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (i < n) atomicAdd(&count[keys[i]], 1u);
+}
+
+void wsk_view_count(hipStream_t s, const uint32_t *keys, uint32_t *count, uint32_t n)
+{
+    hipLaunchKernelGGL(k_view_count, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, keys, count, n);
 }
 
 // stable order inside each bucket: ascending particle id
@@ -1698,6 +1761,182 @@ void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_
 {
     if (!n) return;
     hipLaunchKernelGGL(k_upload_positions_ids, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, xyz_dev, ids_dev, cur, n);
+}
+
+// ---------------------------------------------------------------------------------
+// slab handles: the id-ordered GLOBAL views and loads of the C ABI (ws_read_positions / ws_read_speeds /
+// ws_read_particles / ws_reset / ws_write_particles / a re-grid on ws_set_params), which the reference's host uses every
+// frame (update(), src/fluid_compute.rs:478-485) and on Space (despawn_liquid, :505-525).  Reads: every slab packs
+// {id, payload} records of the particles it owns, the records are all-gathered, and every rank scatters them by id.
+// Loads: every rank is handed the same global array and keeps the particles whose x layer falls into its cuts.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t slab_owner(const WsDev &d, const uint32_t *__restrict__ cuts, uint32_t world, float x)
+{
+    const uint32_t gxg = (uint32_t)grid_layer_x(d, x);
+    uint32_t dest = 0;
+    while (dest + 1 < world && gxg >= cuts[dest + 1]) dest++;
+    return dest;
+}
+
+// payload of one gathered record (after its id word)
+enum { WS_PACK_POS = 0, WS_PACK_SPEED = 1, WS_PACK_RECORD = 2, WS_PACK_STATE = 3, WS_PACK_KEY = 4 };
+__host__ __device__ constexpr uint32_t ws_pack_words(int kind)
+{
+    return kind == WS_PACK_POS ? 3u : kind == WS_PACK_SPEED ? 1u : kind == WS_PACK_RECORD ? 20u : kind == WS_PACK_STATE ? 9u : 1u;
+}
+uint32_t wsk_pack_words(int kind) { return ws_pack_words(kind); }
+
+template <int KIND>
+__global__ void __launch_bounds__(WS_BLOCK) k_slab_pack(WsDev d, WsSoA cur, WsSorted srt, const float4 *__restrict__ accel,
+                                                        int have_step, uint32_t *__restrict__ out)
+{
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (k >= d.n) return;
+    const uint32_t i = d.base + k;
+    constexpr uint32_t W = ws_pack_words(KIND) + 1u;
+    uint32_t *rec = out + (size_t)k * W;
+    float *f = reinterpret_cast<float *>(rec + 1);
+    if constexpr (KIND == WS_PACK_KEY) {
+        // the reference's particle_cell_indicies entry: hash of the cell of the predicted position the last step started from
+        const float4 q = srt.pred(i);
+        rec[0] = __float_as_uint(srt.pos[i].w);
+        rec[1] = ref_hash_key(d, q.x, q.y, q.z);
+        return;
+    }
+    const float4 p = cur.pos[i];
+    rec[0] = __float_as_uint(p.w);
+    if constexpr (KIND == WS_PACK_POS) {
+        f[0] = p.x; f[1] = p.y; f[2] = p.z;
+    } else if constexpr (KIND == WS_PACK_SPEED) {
+        const float4 v = cur.vel[i];
+        f[0] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    } else if constexpr (KIND == WS_PACK_STATE) {
+        const float4 v = cur.vel[i], q = cur.pred[i];
+        f[0] = p.x; f[1] = p.y; f[2] = p.z;
+        f[3] = v.x; f[4] = v.y; f[5] = v.z;
+        f[6] = q.x; f[7] = q.y; f[8] = q.z;
+    } else {  // the 80-byte record (k_gather_slab's fields)
+        const float4 v = cur.vel[i], q = cur.pred[i];
+        float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have_step) {
+            dp.x = srt.pred(i).w;
+            dp.y = srt.vel(i).w;
+            dp.z = d.pressure_scalar * (dp.x - d.target_density);
+            dp.w = d.near_pressure_scalar * dp.y;
+            a = accel[i];
+        }
+        f[0] = p.x; f[1] = p.y; f[2] = p.z; f[3] = 0.f;
+        f[4] = dp.x; f[5] = dp.y; f[6] = dp.z; f[7] = dp.w;
+        f[8] = v.x; f[9] = v.y; f[10] = v.z; f[11] = 0.f;
+        f[12] = a.x; f[13] = a.y; f[14] = a.z; f[15] = 0.f;
+        f[16] = q.x; f[17] = q.y; f[18] = q.z; f[19] = 0.f;
+    }
+}
+
+void wsk_slab_pack(hipStream_t s, const WsDev &d, int kind, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
+                   uint32_t *out)
+{
+    if (!d.n) return;
+    const dim3 g(cdiv(d.n, WS_BLOCK)), b(WS_BLOCK);
+    const int hs = have_step ? 1 : 0;
+    switch (kind) {
+        case WS_PACK_POS: hipLaunchKernelGGL(k_slab_pack<WS_PACK_POS>, g, b, 0, s, d, cur, srt, accel, hs, out); break;
+        case WS_PACK_SPEED: hipLaunchKernelGGL(k_slab_pack<WS_PACK_SPEED>, g, b, 0, s, d, cur, srt, accel, hs, out); break;
+        case WS_PACK_RECORD: hipLaunchKernelGGL(k_slab_pack<WS_PACK_RECORD>, g, b, 0, s, d, cur, srt, accel, hs, out); break;
+        case WS_PACK_STATE: hipLaunchKernelGGL(k_slab_pack<WS_PACK_STATE>, g, b, 0, s, d, cur, srt, accel, hs, out); break;
+        default: hipLaunchKernelGGL(k_slab_pack<WS_PACK_KEY>, g, b, 0, s, d, cur, srt, accel, hs, out); break;
+    }
+}
+
+// every rank's records (rank r: cnt[4 r] of them at all + r * stride_words) scattered by id: out[id * pw + j]
+__global__ void __launch_bounds__(WS_BLOCK) k_slab_unpack_by_id(const uint32_t *__restrict__ all, const uint32_t *__restrict__ cnt,
+                                                                uint32_t max_n, size_t stride_words, uint32_t pw,
+                                                                uint32_t n_global, uint32_t *__restrict__ out)
+{
+    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x, r = blockIdx.y;
+    if (k >= min(cnt[4 * r], max_n)) return;
+    const uint32_t *rec = all + (size_t)r * stride_words + (size_t)k * (pw + 1u);
+    const uint32_t id = rec[0];
+    if (id >= n_global) return;
+    for (uint32_t j = 0; j < pw; j++) out[(size_t)id * pw + j] = rec[1 + j];
+}
+
+void wsk_slab_unpack_by_id(hipStream_t s, const uint32_t *all, const uint32_t *cnt, uint32_t world, uint32_t max_n,
+                           size_t stride_words, uint32_t pw, uint32_t n_global, uint32_t *out)
+{
+    if (!max_n) return;
+    hipLaunchKernelGGL(k_slab_unpack_by_id, dim3(cdiv(max_n, WS_BLOCK), world), dim3(WS_BLOCK), 0, s, all, cnt, max_n,
+                       stride_words, pw, n_global, out);
+}
+
+// Loads.  One lane per record of a chunk of a GLOBAL array; the lanes whose particle this slab owns append it to the
+// owned range (one atomic per wave; the order is free: the sort is canonical).  dyn[DY_N] is the fill counter.
+//   SRC 0: positions at rest (float xyz; id = id0 + t)            -- ws_reset / FluidParticle::make_vec_from_positions
+//   SRC 1: 80-byte records (id = id0 + t)                          -- ws_write_particles
+//   SRC 2: gathered {id, pos, vel, pred} records of every rank     -- a re-grid (blockIdx.y = source rank)
+template <int SRC>
+__global__ void __launch_bounds__(WS_BLOCK) k_slab_select(WsDev d, const uint32_t *__restrict__ cuts, uint32_t world,
+                                                          uint32_t me, const void *__restrict__ chunk, uint32_t id0, uint32_t m,
+                                                          const uint32_t *__restrict__ cnt, size_t stride_words, WsSoA cur,
+                                                          uint32_t cap, uint32_t *__restrict__ dyn)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    bool mine = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p, q = p;
+    uint32_t id = 0;
+    if constexpr (SRC == 2) {
+        const uint32_t r = blockIdx.y;
+        if (t < min(cnt[4 * r], m)) {
+            const uint32_t *rec = static_cast<const uint32_t *>(chunk) + (size_t)r * stride_words + (size_t)t * 10u;
+            const float *f = reinterpret_cast<const float *>(rec + 1);
+            id = rec[0];
+            p = make_float4(f[0], f[1], f[2], 0.f);
+            v = make_float4(f[3], f[4], f[5], 0.f);
+            q = make_float4(f[6], f[7], f[8], 0.f);
+            mine = true;
+        }
+    } else if (t < m) {
+        id = id0 + t;
+        if constexpr (SRC == 0) {
+            const float *f = static_cast<const float *>(chunk) + 3 * (size_t)t;
+            p = q = make_float4(f[0], f[1], f[2], 0.f);
+        } else {
+            const float4 *rec = reinterpret_cast<const float4 *>(static_cast<const ws_particle80 *>(chunk) + t);
+            p = rec[0]; v = rec[2]; q = rec[4];
+        }
+        mine = true;
+    }
+    // ownership follows the PREDICTED position: it is what the step bins by (simulation.wgsl:139)
+    mine = mine && slab_owner(d, cuts, world, q.x) == me;
+    const unsigned long long sel = __ballot(mine);
+    if (!sel) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)sel) - 1;
+    uint32_t first = 0;
+    if (lane == leader) first = atomicAdd(&dyn[DY_N], (uint32_t)__popcll(sel));
+    first = __shfl(first, leader, 64);
+    if (!mine) return;
+    const uint32_t slot = first + (uint32_t)__popcll(sel & ((1ull << lane) - 1ull));
+    if (slot >= cap) {  // counted, not stored: the host sees DY_N > cap and fails the load
+        return;
+    }
+    const uint32_t i = d.base + slot;
+    cur.pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+    cur.vel[i] = make_float4(v.x, v.y, v.z, 0.f);
+    cur.pred[i] = make_float4(q.x, q.y, q.z, 0.f);
+}
+
+void wsk_slab_select(hipStream_t s, const WsDev &d, int src, const uint32_t *cuts, uint32_t world, uint32_t me,
+                     const void *chunk, uint32_t id0, uint32_t m, const uint32_t *cnt, size_t stride_words, WsSoA cur,
+                     uint32_t cap, uint32_t *dyn)
+{
+    if (!m) return;
+    const dim3 b(WS_BLOCK);
+    if (src == 0)
+        hipLaunchKernelGGL(k_slab_select<0>, dim3(cdiv(m, WS_BLOCK)), b, 0, s, d, cuts, world, me, chunk, id0, m, cnt, stride_words, cur, cap, dyn);
+    else if (src == 1)
+        hipLaunchKernelGGL(k_slab_select<1>, dim3(cdiv(m, WS_BLOCK)), b, 0, s, d, cuts, world, me, chunk, id0, m, cnt, stride_words, cur, cap, dyn);
+    else
+        hipLaunchKernelGGL(k_slab_select<2>, dim3(cdiv(m, WS_BLOCK), world), b, 0, s, d, cuts, world, me, chunk, id0, m, cnt, stride_words, cur, cap, dyn);
 }
 
 // ---------------------------------------------------------------------------------

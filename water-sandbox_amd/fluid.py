@@ -330,8 +330,7 @@ class FluidWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        names = ["mask_overflow"]
-        return {k: int(out[i]) for i, k in enumerate(names)}
+        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4])}
 
     def profile(self):
         """{kernel name: (total_ms, launches)} since the last profile_reset (needs profile=True)."""

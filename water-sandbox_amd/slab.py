@@ -15,6 +15,7 @@ Transports:
 """
 import contextlib
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -215,7 +216,8 @@ class LoopbackHub:
 
     def __init__(self, world):
         self.world = world
-        self.barrier = threading.Barrier(world)
+        self.barrier = threading.Barrier(world, timeout=float(os.environ.get("WS_LOOPBACK_TIMEOUT", "300")))  # a rank left
+        # alone in a collective (a protocol bug) breaks the barrier instead of hanging the process
         self.slots = [None] * world
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
@@ -316,9 +318,60 @@ class SlabWorker:
         return int(self._L.ws_num_particles(self._h))
 
     def set_params(self, params):
-        """ws_set_params on a slab handle (everything but the smoothing radius / container: the slab grid is fixed)."""
+        """ws_set_params on a slab handle.  A new smoothing radius / container is COLLECTIVE (every rank makes the same
+        call): the cell grid, the cuts and every slab's particle set are rebuilt."""
         self._check(self._L.ws_set_params(self._h, C.byref(params)))
         self.params = params
+
+    # ---- the host's per-frame calls on a slab handle: global, id-ordered, COLLECTIVE (every rank calls them at the
+    #      same point; every rank gets the whole array) -- update() / despawn_liquid of src/fluid_compute.rs:468-525
+    def read_positions(self, want=True):
+        out = np.empty((self.n_global, 3), np.float32) if want else None
+        self._check(self._L.ws_read_positions(self._h, out.ctypes.data if want else None))
+        return out
+
+    def read_positions_begin(self, buf):
+        assert buf.dtype == np.float32 and buf.shape == (self.n_global, 3) and buf.flags.c_contiguous
+        self._check(self._L.ws_read_positions_begin(self._h, buf.ctypes.data))
+
+    def read_positions_end(self):
+        self._check(self._L.ws_read_positions_end(self._h))
+
+    def read_speeds(self):
+        out = np.empty(self.n_global, np.float32)
+        self._check(self._L.ws_read_speeds(self._h, out.ctypes.data))
+        return out
+
+    def read_vec(self, name="particles"):
+        if name != "particles":
+            raise KeyError(name)
+        out = np.empty(self.n_global, fluid.PARTICLE_DTYPE)
+        self._check(self._L.ws_read_particles(self._h, out.ctypes.data))
+        return out
+
+    def reset(self, positions):
+        """ws_reset: `positions` = ALL n_global initial positions (the same array on every rank)."""
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        assert positions.shape[0] == self.n_global
+        self._check(self._L.ws_reset(self._h, positions.ctypes.data))
+
+    def write_particles(self, records):
+        """ws_write_particles: `records` = ALL n_global 80-byte records in id order (the same array on every rank)."""
+        records = np.ascontiguousarray(records, fluid.PARTICLE_DTYPE)
+        assert records.shape[0] == self.n_global
+        self._check(self._L.ws_write_particles(self._h, records.ctypes.data))
+
+    def sort_view(self):
+        keys = np.empty(self.n_global, np.uint32)
+        perm = np.empty(self.n_global, np.uint32)
+        off = np.empty(self.n_global, np.uint32)
+        self._check(self._L.ws_read_sort_view(self._h, keys.ctypes.data, perm.ctypes.data, off.ctypes.data))
+        return keys, perm, off
+
+    def stats(self):
+        out = np.zeros(16, np.uint32)
+        self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
+        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4])}
 
     def counters(self):
         """Migration counters since creation (ws_slab_counters): owned now, left, arrived, left by the far route."""
@@ -361,14 +414,48 @@ class SlabWorker:
             pass
 
 
+def run_loopback_program(positions, params, world, program, device=0, **kw):
+    """`world` slabs of one domain inside this process (one thread per slab); every thread runs `program(worker, rank)`
+    -- the host's frame loop, written once against the worker interface -- and the results of all ranks are returned
+    ([program's return value per rank]).  The loopback transport's barrier breaks (instead of hanging) when a rank
+    leaves a collective alone."""
+    positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    n = positions.shape[0]
+    owner = assign(params, positions, world)
+    hub = LoopbackHub(world)
+    results, errors = [None] * world, []
+
+    def body(r):
+        try:
+            sel = np.flatnonzero(owner == r).astype(np.uint32)
+            w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device, **kw)
+            results[r] = program(w, r)
+            w.close()
+        except Exception as e:  # pragma: no cover - surfaced by the caller
+            errors.append((r, e))
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise RuntimeError("slab thread failed: %r" % (errors,))
+    return results
+
+
 def run_loopback(positions, params, world, steps, device=0, ieee_division=False, capacity=0, ghost_capacity=0,
-                 collect_errors=False, counters=None, change_params=None):
+                 collect_errors=False, counters=None, change_params=None, sync_every_step=False, state=None):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
     particles of all slabs merged into original-id order.  Test helper for one-GPU boxes.
     collect_errors: instead of raising, return {rank: (steps completed, exception)} for the slabs whose ws_step
     failed (the capacity tests expect every rank to fail alike).
     counters: a dict that receives {rank: SlabWorker.counters()} taken after the last step.
-    change_params: (step, params) -- every slab calls ws_set_params(params) after `step` steps."""
+    change_params: (step, params) -- every slab calls ws_set_params(params) after `step` steps.
+    sync_every_step (with collect_errors): ws_sync after every ws_step, as a frame loop that reads every frame does;
+    what ws_sync reports is recorded under the key (rank, "sync") and the rank goes on stepping.
+    state: 80-byte records (original-id order) to start from instead of positions at rest."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     n = positions.shape[0]
     owner = assign(params, positions, world)
@@ -383,6 +470,8 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
             sel = np.flatnonzero(owner == r).astype(np.uint32)
             w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device,
                            ieee_division=ieee_division, capacity=capacity, ghost_capacity=ghost_capacity)
+            if state is not None:
+                w.write_particles(state)
             if collect_errors:
                 for k in range(steps):
                     try:
@@ -391,6 +480,11 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
                         errors.append((r, (k, e)))
                         w.close()
                         return
+                    if sync_every_step:
+                        try:
+                            w.sync()
+                        except fluid.WsError as e:
+                            errors.append(((r, "sync"), (k, e)))
             elif change_params is not None:
                 w.run(change_params[0])
                 w.set_params(change_params[1])
