@@ -46,7 +46,13 @@ HBM_COPY_GBS = 6290.0  # achievable: float4 copy measured on MI355X (MI355X_MICR
 C3_PARTICLES = 4194304
 SETTLED_FROM = 400     # first step of the settled window
 SETTLED_STEPS = 100
-PROFILES = os.path.join(ROOT, "profiles", "r02")
+PROFILES_ROUND = "r03"
+PROFILES = os.path.join(ROOT, "profiles", PROFILES_ROUND)
+# VALU issue peak of the chip: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (a packed-f32 or
+# transcendental instruction takes more: the fraction below is a lower bound of how busy the VALU issue ports are)
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
+STEP_KERNELS = {"cell_scan": "k_scan<true>", "cell_scatter": "k_place", "reorder": "k_reorder<true>",
+                "density": "k_density_listed<false>", "force_integrate_bin": "k_force_listed<false, false>"}
 
 KERNEL_LABEL = {
     "density": "density (K4 update_density: radius sweep + accept masks)",
@@ -64,6 +70,10 @@ def parse_args():
     ap.add_argument("--replicate", action="store_true",
                     help="N GPUs: the config replicated N times along x (e.g. --config c3 --replicate: 4 194 304 "
                          "particles per GPU at every N) instead of BASELINE.json's C4 / C5 geometry")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the whole measurement (fresh trajectory each: W warm-up steps, K timed steps, the "
+                         "run-up to the settled window and its 100 timed steps); the line reports the MEDIAN repetition "
+                         "(SURVEY 8(d) / BASELINE.md protocol) and lists all of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settled", action="store_true", help="skip the settled-state window (steps 400..500)")
     ap.add_argument("--no-readback", action="store_true",
@@ -90,24 +100,21 @@ def cpu_baseline(pos, params, steps):
     for _ in range(steps):
         orc.step(O.SORT_FAST)
     dt = time.perf_counter() - t0
-    try:
-        share = len(os.sched_getaffinity(0))
-    except AttributeError:
-        share = os.cpu_count() or 1
+    share, why = O.cpu_share()
     return {
         "value": steps / dt,
         "unit": "steps/s",
         "cores": O.default_threads(),
         "kind": "port",
         "sample": "%d full steps of the same %d-particle workload after 1 warm-up step (CPU restatement of the "
-        "reference WGSL, fast sort mode; %d OpenMP threads of the %d cores this process may run on)"
-        % (steps, orc.n, O.default_threads(), share),
+        "reference WGSL, fast sort mode; %d OpenMP threads = every core this process may use: %s)"
+        % (steps, orc.n, O.default_threads(), why),
     }
 
 
 def load_traffic(config, dist, warmup, steps, kernel):
     """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc pass of EXACTLY this window
-    (profiles/r02/traffic.json, key '<config>-<dist>-w<warmup>-k<steps>'), with its provenance -- or (None, None)
+    (profiles/rNN/traffic.json, key '<config>-<dist>-w<warmup>-k<steps>'), with its provenance -- or (None, None)
     when no pass of this window is committed.  Never filled from another window."""
     path = os.path.join(PROFILES, "traffic.json")
     key = "%s-%s-w%d-k%d" % (config, dist, warmup, steps)
@@ -117,9 +124,65 @@ def load_traffic(config, dist, warmup, steps, kernel):
         v = t.get(key, {}).get("bytes_per_launch", {}).get(kernel)
         if v is None:
             return None, None
-        return v, "profiles/r02/traffic.json[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this window" % key
+        return v, "profiles/%s/traffic.json[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this window" % (PROFILES_ROUND, key)
     except (OSError, ValueError):
         return None, None
+
+
+def load_window_counters(config, dist, warmup, steps):
+    """Everything the committed counter passes of EXACTLY this window hold (profiles/rNN/traffic.json: FETCH_SIZE /
+    WRITE_SIZE per kernel; profiles/rNN/pmc_windows.json: SQ / TA counters per kernel), or {}."""
+    key = "%s-%s-w%d-k%d" % (config, dist, warmup, steps)
+    out = {}
+    for name in ("traffic.json", "pmc_windows.json"):
+        try:
+            with open(os.path.join(PROFILES, name)) as f:
+                out[name] = json.load(f).get(key)
+        except (OSError, ValueError):
+            out[name] = None
+    return out
+
+
+def step_traffic(counters, ms_per_step):
+    """Counter-measured HBM bytes of ALL five kernels of a step (2 x FETCH_SIZE + WRITE_SIZE each, the gfx950 half-count
+    correction of MI355X_MICROARCH.md applied to every kernel) over the step time, against the measured float4-copy
+    rate: the measured-bytes view of the WHOLE step."""
+    t = counters.get("traffic.json")
+    if not t:
+        return None
+    per = {}
+    for label, kname in STEP_KERNELS.items():
+        f, w = t["fetch_raw"].get(kname), t["write_raw"].get(kname)
+        if f is None or w is None:
+            return None
+        per[label] = 2.0 * f + w
+    total = sum(per.values())
+    gbps = total / (ms_per_step * 1e-3) / 1e9
+    return {"bytes_per_step": total, "bytes_per_kernel": per, "GBps": gbps, "frac_of_measured_copy_bw": gbps / HBM_COPY_GBS,
+            "source": "profiles/%s/traffic.json (2 x FETCH_SIZE + WRITE_SIZE of the five step kernels) / this run's ms_per_step"
+                      % PROFILES_ROUND}
+
+
+def secondary_roofline(counters, label, avg_s):
+    """What the counters say bounds the kernel: VALU issue (wave-instructions per second against the chip's issue peak)
+    with the scalar instruction stream, the lane utilisation and the texture-addresser busy fraction next to it."""
+    p = (counters.get("pmc_windows.json") or {}).get(STEP_KERNELS[label])
+    if not p or avg_s <= 0:
+        return None
+    valu = p.get("SQ_INSTS_VALU")
+    if valu is None:
+        return None
+    out = {"resource": "valu_issue", "achieved": valu / avg_s, "peak": VALU_PEAK_WAVE_INSTR_PER_S, "unit": "wave-instr/s",
+           "frac": valu / avg_s / VALU_PEAK_WAVE_INSTR_PER_S, "valu_wave_instr_per_launch": valu,
+           "salu_wave_instr_per_launch": p.get("SQ_INSTS_SALU"),
+           "source": "profiles/%s/pmc_windows.json (rocprofv3 --pmc passes of this window) / this run's launch time" % PROFILES_ROUND}
+    if p.get("SQ_THREAD_CYCLES_VALU") and p.get("SQ_ACTIVE_INST_VALU"):
+        out["lane_utilisation"] = p["SQ_THREAD_CYCLES_VALU"] / 64.0 / p["SQ_ACTIVE_INST_VALU"]
+    if p.get("TA_BUSY_avr") is not None and p.get("GRBM_GUI_ACTIVE"):
+        out["texture_addresser_busy_frac"] = p["TA_BUSY_avr"] / p["GRBM_GUI_ACTIVE"]
+    elif p.get("ta_busy_frac") is not None:
+        out["texture_addresser_busy_frac"] = p["ta_busy_frac"]
+    return out
 
 
 NEIGHBOUR_KERNELS = ("density", "force_integrate_bin")
@@ -139,6 +202,8 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed, dominant)
     alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     traffic, source = (None, None) if distributed else load_traffic(config, dist, warmup, steps, dominant)
+    counters = {} if distributed else load_window_counters(config, dist, warmup, steps)
+    secondary = secondary_roofline(counters, dominant, avg_s)
     # the measured-bytes view SURVEY 8(d) asks for next to the algorithmic one: counter bytes per launch over this
     # run's launch time, against the float4-copy rate measured on MI355X (MI355X_MICROARCH.md: 6.29 TB/s)
     measured = traffic / avg_s / 1e9 if traffic and avg_s > 0 else None
@@ -151,8 +216,15 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed, dominant)
         "dominance": "most time over all timed windows of this run",
         "other": {"kernel": KERNEL_LABEL[other], "avg_launch_ms": o_avg * 1e3, "alg_bytes_per_launch": o_alg,
                   "achieved": o_alg / o_avg / 1e9 if o_avg > 0 else 0.0,
-                  "frac": (o_alg / o_avg / 1e9 if o_avg > 0 else 0.0) / HBM_PEAK_GBS},
+                  "frac": (o_alg / o_avg / 1e9 if o_avg > 0 else 0.0) / HBM_PEAK_GBS,
+                  "traffic": (counters.get("traffic.json") or {}).get("bytes_per_launch", {}).get(other),
+                  "secondary": secondary_roofline(counters, other, o_avg)},
+        # `bound` names the roofline this object prices the kernel against (the contract's HBM roofline, by algorithmic
+        # bytes).  It is NOT what limits the kernel: the counters say VALU issue and the texture addresser (`limiter`,
+        # `secondary`), and its real HBM traffic is `traffic` (about 1 x the algorithmic bytes).
         "bound": "hbm",
+        "limiter": "valu_issue + texture_addresser (divergent 16-B gathers), not HBM: see `secondary`; DESIGN.md 5",
+        "secondary": secondary,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -274,20 +346,41 @@ def main():
             elapsed = float(t.item())
         return elapsed, worker.profile()
 
-    worker = make_worker()
-    worker.profile_select(neighbour_mask)
-    worker.run(args.warmup)
-    elapsed, prof = timed_window(worker, args.steps)
-    owned = worker.num_owned() if distributed else n_global
-    breakdown = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]}
+    def one_repetition():
+        """A fresh trajectory: W untimed warm-up steps, EXACTLY K timed steps, then (same handle) on to step 400 and the
+        100 timed steps of the settled window."""
+        worker = make_worker()
+        worker.profile_select(neighbour_mask)
+        worker.run(args.warmup)
+        elapsed, prof = timed_window(worker, args.steps)
+        rep = {"elapsed": elapsed, "prof": prof, "owned": worker.num_owned() if distributed else n_global}
+        done = args.warmup + args.steps
+        if not args.no_settled and done <= SETTLED_FROM:
+            worker.run(SETTLED_FROM - done)
+            rep["s_elapsed"], rep["s_prof"] = timed_window(worker, SETTLED_STEPS)
+            rep["s_owned"] = worker.num_owned() if distributed else n_global
+        return worker, rep
 
+    reps = []
+    worker = None
+    for _ in range(max(1, args.reps)):
+        if worker is not None:
+            worker.close()
+        worker, rep = one_repetition()
+        reps.append(rep)
+
+    def median_of(key):
+        order = sorted(range(len(reps)), key=lambda i: reps[i][key])
+        return reps[order[len(order) // 2]]
+
+    first = median_of("elapsed")  # the repetition with the median time of the first window
+    elapsed, prof, owned = first["elapsed"], first["prof"], first["owned"]
+    breakdown = {k: (v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]}
     settled = None
     s_prof = None
-    done = args.warmup + args.steps
-    if not args.no_settled and done <= SETTLED_FROM:
-        worker.run(SETTLED_FROM - done)
-        s_elapsed, s_prof = timed_window(worker, SETTLED_STEPS)
-        s_owned = worker.num_owned() if distributed else n_global
+    if "s_elapsed" in reps[0]:
+        sm = median_of("s_elapsed")
+        s_elapsed, s_prof, s_owned = sm["s_elapsed"], sm["s_prof"], sm["s_owned"]
     # one dominant kernel for the whole run: per-launch means weighted by the windows' step counts
     dominant = dominant_kernel(*([(prof, args.steps)] + ([(s_prof, SETTLED_STEPS)] if s_prof is not None else [])))
     roof = roofline_of(prof, owned, cfg_name, args.dist, args.warmup, args.steps, distributed, dominant)
@@ -298,9 +391,13 @@ def main():
             "steps": SETTLED_STEPS,
             "ms_per_step": s_elapsed / SETTLED_STEPS * 1e3,
             "global_steps_per_s": SETTLED_STEPS / s_elapsed,
+            "repetitions_ms_per_step": [r["s_elapsed"] / SETTLED_STEPS * 1e3 for r in reps],
             "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in s_prof.items() if v[1]},
             "roofline": roofline_of(s_prof, s_owned, cfg_name, args.dist, SETTLED_FROM, SETTLED_STEPS, distributed, dominant),
         }
+        if not distributed:
+            settled["step_traffic"] = step_traffic(load_window_counters(cfg_name, args.dist, SETTLED_FROM, SETTLED_STEPS),
+                                                   settled["ms_per_step"])
     if args.breakdown and not distributed and rank == 0:
         worker.profile_select(0xFFFFFFFF)
         worker.profile_reset()
@@ -393,7 +490,11 @@ def main():
             "c3_equivalent_steps_per_s": shares * global_steps_per_s,
             "particle_steps_per_s": global_steps_per_s * n_global,
             "algorithmic_GBps_step": B_ALG_STEP * n_global * global_steps_per_s / 1e9,
+            "repetitions": {"count": len(reps), "reported": "the repetition with the median time (each window on its own)",
+                            "ms_per_step": [r["elapsed"] / args.steps * 1e3 for r in reps]},
             "roofline": roof,
+            "step_traffic": None if distributed else step_traffic(
+                load_window_counters(cfg_name, args.dist, args.warmup, args.steps), elapsed / args.steps * 1e3),
             "kernel_ms": breakdown,
             "settled": settled,
         }

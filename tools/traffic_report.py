@@ -31,7 +31,7 @@ dens = [k for k in fetch if k.startswith("k_density")][0]
 out["bytes_per_launch"] = {"force_integrate_bin": 2.0 * fetch[force] + write[force],
                            "density": 2.0 * fetch[dens] + write[dens]}
 out["bytes_per_launch_note"] = "2 x FETCH_SIZE (gfx950 half-count correction for 16-B/lane reads) + WRITE_SIZE"
-path = out_path or os.path.join(root, "profiles", "r02", "traffic.json")
+path = out_path or os.path.join(root, "profiles", "r03", "traffic.json")
 allt = json.load(open(path)) if os.path.exists(path) else {}
 allt["%s-%s-w%d-k%d" % (cfg, dist, warm, steps)] = out  # keyed by window: bench.py fills roofline.traffic on an exact match only
 json.dump(allt, open(path, "w"), indent=1, sort_keys=True)
