@@ -243,6 +243,10 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
                                    ws_transport *out);
 void ws_rccl_transport_destroy(ws_transport *t);
 const char *ws_rccl_last_error(void);
+/* Communicators the transport drives: 2 = the step's two streams (migration / all-gather on the handle's stream, halos on
+ * its communication stream) each keep to a communicator of their own (the second one is split off the first), so no
+ * communicator ever sees operations from two streams; 1 = WS_RCCL_SINGLE_COMM=1 or an RCCL without ncclCommSplit. */
+uint32_t ws_rccl_transport_communicators(const ws_transport *t);
 
 /* Host-only: which slab owns each position (by the x cell of floor(x / h) in the global grid, equal
  * cell-count cuts S_r = r * nx / world_size).  out_rank holds n entries. */

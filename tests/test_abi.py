@@ -152,3 +152,19 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.split()[:3] == ["0.016667", "2444.620", "7.9"]
+
+
+def test_no_smoothing_radius_runs_out_of_cell_tables(ws):
+    """Host-only (ws_slab_assign derives the global grid): every radius a HUD key press can reach at any BASELINE
+    config yields a grid (merged cells beyond the budget), never WS_ERR_OUT_OF_MEMORY; a radius so small that cell
+    coordinates stop being exact in f32 is an invalid argument, not an allocation failure."""
+    lib = ws.load_library()
+    lib.ws_slab_assign.argtypes = [C.POINTER(ws.fluid.WsParams), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    pos = np.zeros((4, 3), np.float32)
+    out = np.zeros(4, np.uint32)
+    for name in ("c3", "c4", "c5"):
+        for h in (0.35, 0.25, 0.15, 0.05, 0.01):
+            p = ws.make_params(container_size=ws.workloads.CONFIGS[name][1], smoothing_radius=h)
+            assert lib.ws_slab_assign(C.byref(p), pos.ctypes.data, 4, 2, out.ctypes.data) == 0, (name, h)
+    p = ws.make_params(container_size=ws.workloads.CONFIGS["c5"][1], smoothing_radius=1e-6)
+    assert lib.ws_slab_assign(C.byref(p), pos.ctypes.data, 4, 2, out.ctypes.data) == 1  # WS_ERR_INVALID_ARG

@@ -433,14 +433,30 @@ ws_status refresh_accel(ws_handle *h)
 {
     if (!h->accel_stale) return WS_OK;
     WsDev d = h->dev;
+    auto pass = [&](const WsDev &dd) {
+        if (dd.n)
+            wsk_force(h->stream, dd, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
+                      h->variant, h->ieee, h->mask, true);
+    };
     if (h->slab) {
-        d.dyn = h->slab->dyn;
-        d.range_sel = 0;
-        d.n = h->slab->cap;  // upper bound; the kernel reads the owned count from the device
+        const WsSlab *S = h->slab;
+        d.dyn = S->dyn;
+        d.n = S->cap;  // upper bound; the kernel reads the owned count from the device
+        if (S->last_split) {
+            // the step ran K4 / K5 as an early and a late launch, and the early ones number their candidates on runs cut
+            // to the owned range (ws_kernels.hip ws_cut): walk the same masks the same way
+            d.range_sel = WS_RANGE_EARLY;
+            pass(d);
+            d.range_sel = d.has_left && d.has_right ? WS_RANGE_LATE_BOTH : d.has_left ? WS_RANGE_LATE_LEFT : WS_RANGE_LATE_RIGHT;
+            d.n = (uint32_t)std::min<uint64_t>(S->cap, 2ull * S->halo_cap);
+            pass(d);
+        } else {
+            d.range_sel = WS_RANGE_ALL;
+            pass(d);
+        }
+    } else {
+        pass(d);
     }
-    if (d.n)
-        wsk_force(h->stream, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->ieee, h->mask, true);
     HIP_TRY(h, hipGetLastError());
     h->accel_stale = false;
     return WS_OK;

@@ -77,7 +77,8 @@ enum {
     WS_DYN_ERR_MIGRATION = 1u,  // more leavers than a migration message holds
     WS_DYN_ERR_CAPACITY = 2u,   // owned count would exceed the slab's capacity
     WS_DYN_ERR_HALO = 4u,       // a boundary layer holds more particles than a halo message
-    WS_DYN_ERR_GHOSTS = 8u      // more ghosts than the ghost range holds
+    WS_DYN_ERR_GHOSTS = 8u,     // more ghosts than the ghost range holds
+    WS_DYN_ERR_STAMP = 16u      // a message stamped with another step arrived: the transport delivered out of order
 };
 enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LATE_RIGHT = 3, WS_RANGE_LATE_BOTH = 4 };
 #define WS_HDR_WORDS_HOST 4u  // words of a message header (ws_kernels.hip WS_HDR_WORDS)
@@ -251,6 +252,7 @@ struct WsSlab {
     hipStream_t comm = nullptr, copy = nullptr;
     hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr, ev_filled = nullptr;
     bool overlap = true;              // WS_SLAB_OVERLAP=0 turns it off
+    bool last_split = false;          // the last step ran K4 / K5 as early + late launches (refresh_accel repeats that)
     // cumulative statistics (refreshed by ws_slab_read_particles)
     uint64_t migrated_out = 0;
 };
@@ -298,7 +300,8 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
 void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
                    uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities, uint32_t step);
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,
-                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities);
+                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities,
+                     uint32_t step);
 void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids);
 void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);

@@ -1504,7 +1504,12 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
     if (tid < world) {
         const uint32_t *msg = far_all + (size_t)tid * far_words;
         for (uint32_t w = 0; w < WS_HDR_WORDS; w++) status[tid * WS_HDR_WORDS + w] = msg[w];
+        // Every message carries the step it belongs to.  A transport that keeps its calls in issue order can never
+        // deliver another step's message; if one arrives anyway (two streams driving one communicator out of order, a
+        // rank one step ahead) say so instead of simulating on with it.
+        if (msg[3] != step) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);
     }
+    if (tid == 0 && ((left && recvL[3] != step) || (right && recvR[3] != step))) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);
     __syncthreads();
     const uint32_t nL = left ? min(recvL[0], mig_cap) : 0u, nR = right ? min(recvR[0], mig_cap) : 0u;
     const uint32_t leave = min(dyn[DY_NHOLE], hole_cap);
@@ -1583,6 +1588,8 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         // owned count and the step they describe
         sendL[0] = 0;
         sendR[0] = 0;
+        sendL[3] = step + 1u;
+        sendR[3] = step + 1u;
         far_send[0] = 0;
         far_send[1] = dyn[DY_ERR];
         far_send[2] = n_new;
@@ -1651,7 +1658,7 @@ void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorte
 __global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__restrict__ start, WsSorted srt, WsXYZ sxyz,
                                                           uint32_t *__restrict__ dyn, uint32_t rowy, uint32_t nxl,
                                                           uint32_t ghost_cap, const uint32_t *__restrict__ recvL,
-                                                          const uint32_t *__restrict__ recvR, int densities)
+                                                          const uint32_t *__restrict__ recvR, int densities, uint32_t step)
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     const uint32_t side = blockIdx.y;
@@ -1673,6 +1680,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__r
         if (t == 0) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_GHOSTS);
         g = ghost_cap;
     }
+    if (t == 0 && have && msg[3] != step) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);  // another step's halo (see k_migrate_fill)
     if (t == 0) dyn[side ? DY_GR : DY_GL] = g;
     const uint32_t *slice = msg + WS_HDR_WORDS;
     const uint32_t first_slot = side ? base + n : base - g;
@@ -1704,11 +1712,12 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__r
 }
 
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,
-                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities)
+                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities,
+                     uint32_t step)
 {
     const uint32_t work = densities ? ghost_cap : max(ghost_cap, rowy + (uint32_t)d.guard + 2u);
     hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(work, WS_BLOCK), 2), dim3(WS_BLOCK), 0, s, d, start, srt, sxyz, dyn, rowy, nxl,
-                       ghost_cap, recvL, recvR, densities ? 1 : 0);
+                       ghost_cap, recvL, recvR, densities ? 1 : 0, step);
 }
 
 // Slab readback: owned particles (state of the last step, sorted order) with their ids.

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -25,6 +26,7 @@ struct RcclApi {
     int (*GetUniqueId)(NcclUniqueId *) = nullptr;
     int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommSplit)(NcclComm, int, int, NcclComm *, void *) = nullptr;  // optional (RCCL >= 2.18)
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -63,15 +65,34 @@ bool load_rccl()
         if (!ok) {
             dlclose(g_api.lib);
             g_api.lib = nullptr;
+            return;
         }
+        g_api.CommSplit = reinterpret_cast<decltype(g_api.CommSplit)>(dlsym(g_api.lib, "ncclCommSplit"));
     });
     return g_api.lib != nullptr;
 }
 
+// The slab step drives the transport from TWO streams: migration + the small all-gather (and the host's global reads)
+// on the handle's stream, the two halos on its communication stream, concurrently.  Operations of ONE communicator
+// issued on two streams would depend on RCCL serialising them in host issue order on every rank alike, and would
+// couple the streams again (the next step's migration queuing behind halo B).  So the transport owns two
+// communicators -- the second one split off the first (ncclCommSplit: no second unique-id exchange) -- and every
+// stream keeps to its own: the first stream it sees gets comm[0], any other stream comm[1].
+// WS_RCCL_SINGLE_COMM=1 (or an RCCL without ncclCommSplit) keeps everything on comm[0], the pre-round-3 behaviour.
 struct RcclTransport {
-    NcclComm comm = nullptr;
+    NcclComm comm[2] = {nullptr, nullptr};
+    hipStream_t first_stream = nullptr;
+    bool have_first = false;
     int rank = 0, world = 1, device = 0;
     std::string error;
+    NcclComm on(hipStream_t s)
+    {
+        if (!have_first) {
+            first_stream = s;
+            have_first = true;
+        }
+        return (s == first_stream || !comm[1]) ? comm[0] : comm[1];
+    }
 };
 
 int check(RcclTransport *t, int rc, const char *what)
@@ -91,12 +112,13 @@ int rccl_sendrecv(void *ctx, uint32_t nseg, void *const send_ptr[], const uint64
     bool any = false;
     for (uint32_t i = 0; i < 2 * nseg; i++) any = any || send_bytes[i] || recv_bytes[i];
     if (!any) return 0;
+    NcclComm comm = t->on(s);
     if (check(t, g_api.GroupStart(), "ncclGroupStart")) return 1;
     int rc = 0;
     for (uint32_t i = 0; i < 2 * nseg && !rc; i++) {
         const int peer = (i % 2 == 0) ? t->rank - 1 : t->rank + 1;
-        if (send_bytes[i]) rc = g_api.Send(send_ptr[i], (size_t)send_bytes[i], NCCL_UINT8, peer, t->comm, s);
-        if (!rc && recv_bytes[i]) rc = g_api.Recv(recv_ptr[i], (size_t)recv_bytes[i], NCCL_UINT8, peer, t->comm, s);
+        if (send_bytes[i]) rc = g_api.Send(send_ptr[i], (size_t)send_bytes[i], NCCL_UINT8, peer, comm, s);
+        if (!rc && recv_bytes[i]) rc = g_api.Recv(recv_ptr[i], (size_t)recv_bytes[i], NCCL_UINT8, peer, comm, s);
     }
     const int rc_end = g_api.GroupEnd();
     if (check(t, rc, "ncclSend/ncclRecv")) return 1;
@@ -106,8 +128,8 @@ int rccl_sendrecv(void *ctx, uint32_t nseg, void *const send_ptr[], const uint64
 int rccl_allgather(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream)
 {
     RcclTransport *t = static_cast<RcclTransport *>(ctx);
-    return check(t, g_api.AllGather(send_ptr, recv_ptr, (size_t)bytes_each, NCCL_UINT8, t->comm, static_cast<hipStream_t>(stream)),
-                 "ncclAllGather");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return check(t, g_api.AllGather(send_ptr, recv_ptr, (size_t)bytes_each, NCCL_UINT8, t->on(s), s), "ncclAllGather");
 }
 
 }  // namespace
@@ -136,9 +158,20 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
     t->device = device;
     NcclUniqueId id;
     memcpy(id.internal, unique_id, sizeof id.internal);
-    if (check(t, g_api.CommInitRank(&t->comm, t->world, id, t->rank), "ncclCommInitRank")) {
+    if (check(t, g_api.CommInitRank(&t->comm[0], t->world, id, t->rank), "ncclCommInitRank")) {
+        g_api.error = t->error;
         delete t;
         return WS_ERR_COMM;
+    }
+    const char *single = getenv("WS_RCCL_SINGLE_COMM");
+    if (g_api.CommSplit && !(single && atoi(single) != 0)) {
+        // collective over the first communicator; same colour everywhere, ranks keep their order
+        if (check(t, g_api.CommSplit(t->comm[0], 0, t->rank, &t->comm[1], nullptr), "ncclCommSplit")) {
+            g_api.error = t->error;
+            g_api.CommDestroy(t->comm[0]);
+            delete t;
+            return WS_ERR_COMM;
+        }
     }
     out->ctx = t;
     out->sendrecv = rccl_sendrecv;
@@ -151,11 +184,20 @@ void ws_rccl_transport_destroy(ws_transport *t)
     if (!t || !t->ctx || t->sendrecv != rccl_sendrecv) return;
     RcclTransport *r = static_cast<RcclTransport *>(t->ctx);
     hipSetDevice(r->device);
-    if (r->comm) g_api.CommDestroy(r->comm);
+    if (r->comm[1]) g_api.CommDestroy(r->comm[1]);
+    if (r->comm[0]) g_api.CommDestroy(r->comm[0]);
     delete r;
     t->ctx = nullptr;
 }
 
 const char *ws_rccl_last_error(void) { return g_api.error.c_str(); }
+
+// how many communicators the transport drives (2 = one per stream of the slab step); diagnostics / tests
+uint32_t ws_rccl_transport_communicators(const ws_transport *t)
+{
+    if (!t || !t->ctx || t->sendrecv != rccl_sendrecv) return 0;
+    const RcclTransport *r = static_cast<const RcclTransport *>(t->ctx);
+    return r->comm[1] ? 2u : 1u;
+}
 
 }  // extern "C"

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ws_bit_sorter_stage_count", "ws_status_string", "ws_abi_version", "ws_create", "ws_destroy",
     "ws_step", "ws_ready", "ws_sync", "ws_set_params", "ws_read_positions", "ws_read_particles",
     "ws_reset", "ws_write_particles", "ws_pin_host_buffer", "ws_unpin_host_buffer", "ws_read_speeds", "ws_read_positions_begin", "ws_read_positions_end", "ws_slab_counters", "ws_rccl_unique_id", "ws_rccl_transport_create",
-    "ws_rccl_transport_destroy", "ws_rccl_last_error", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
+    "ws_rccl_transport_destroy", "ws_rccl_last_error", "ws_rccl_transport_communicators", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
     "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
     "ws_grid_dims", "ws_read_stats", "ws_slab_assign", "ws_slab_create", "ws_slab_read_particles",
 ]

@@ -170,6 +170,12 @@ class NativeRcclTransport:
             raise fluid.WsError(st, "ws_rccl_unique_id: " + (L.ws_rccl_last_error() or b"").decode())
         return buf.raw
 
+    def communicators(self):
+        """2 = each of the slab step's two streams has a communicator of its own."""
+        self._L.ws_rccl_transport_communicators.argtypes = [C.POINTER(WsTransport)]
+        self._L.ws_rccl_transport_communicators.restype = C.c_uint32
+        return int(self._L.ws_rccl_transport_communicators(C.byref(self.struct)))
+
     def close(self):
         if self.struct.ctx:
             self._L.ws_rccl_transport_destroy(C.byref(self.struct))
