@@ -153,7 +153,11 @@ ws_status derive_dev(ws_handle *h, const ws_params &p, uint32_t n, WsDev *out)
         // smallest merge factor that brings this axis (and with it the grid) under the budget, at most the whole axis
         uint64_t want = std::max<uint64_t>(budget / std::max<uint64_t>(others, 1), 1);  // grid cells this axis may keep
         uint64_t m = ((uint64_t)d.fdim[c] + want - 1) / want;
-        m = std::min<uint64_t>(std::max<uint64_t>(m, 1), (uint64_t)d.fdim[c]);
+        // y and z keep at least three grid cells: the nine runs of a particle are spans [cc - 1, cc + 1] of the
+        // LINEAR cell index around cc = c + dx * rowy + dy * rowz, which are disjoint only if dim2 >= 3 and dim1 >= 3
+        // (fewer, and z + 1 of one (dx, dy) column IS z - 1 of the next: neighbours would be counted twice)
+        const uint64_t m_max = c == 0 ? (uint64_t)d.fdim[c] : (uint64_t)d.fdim[c] / 3;
+        m = std::min<uint64_t>(std::max<uint64_t>(m, 1), std::max<uint64_t>(m_max, 1));
         d.cm[c] = (int32_t)m;
         d.dim[c] = (int32_t)(((uint64_t)d.fdim[c] + m - 1) / m);
         cells = others * (uint64_t)d.dim[c];
