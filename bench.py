@@ -74,6 +74,9 @@ def parse_args():
                     help="repetitions of the whole measurement (fresh trajectory each: W warm-up steps, K timed steps, the "
                          "run-up to the settled window and its 100 timed steps); the line reports the MEDIAN repetition "
                          "(SURVEY 8(d) / BASELINE.md protocol) and lists all of them")
+    ap.add_argument("--graph", action="store_true",
+                    help="WS_FLAG_GRAPH: replay the step from a captured hipGraph (BASELINE config 5's 'hipGraph-captured step'); "
+                         "per-kernel events are not part of a captured step, so the roofline objects are omitted")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settled", action="store_true", help="skip the settled-state window (steps 400..500)")
     ap.add_argument("--no-readback", action="store_true",
@@ -198,6 +201,8 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed, dominant)
     """The roofline object of one timed window from the HIP events of the two neighbour kernels' launches, for the run's
     dominant kernel; the other neighbour kernel's figures ride along under `other`."""
     ms, cnt = prof[dominant]
+    if not cnt:
+        return None  # --graph: no per-kernel events inside a captured step
     avg_s = ms / max(cnt, 1) * 1e-3
     alg_bytes = KERNEL_ALG_BYTES[dominant] * owned
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -311,14 +316,14 @@ def main():
         def make_worker(ieee=False):
             return ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
                                       stream=None if which == "rccl" else torch.cuda.current_stream().cuda_stream,
-                                      profile=True, ieee_division=ieee)
+                                      profile=not args.graph, ieee_division=ieee, graph=args.graph)
     else:
         cfg_name = base_name = args.config or "c3"
         pos, params = ws.workloads.make_workload(cfg_name, args.dist)
         n_global = pos.shape[0]
 
         def make_worker(ieee=False):
-            return ws.FluidWorker(pos, params, device=local_rank, profile=True, ieee_division=ieee)
+            return ws.FluidWorker(pos, params, device=local_rank, profile=not args.graph, ieee_division=ieee, graph=args.graph)
 
     # HIP events time only the two neighbour kernels inside the timed regions (the start / stop events each launch
     # carries, on the library's stream; a slab step that splits them into early / late ranges records events around
@@ -406,7 +411,7 @@ def main():
         for k, v in sorted(worker.profile().items(), key=lambda kv: -kv[1][0]):
             if v[1]:
                 print("%-22s %9.3f ms" % (k, v[0] / v[1]), file=sys.stderr)
-    stats = worker.stats() if not distributed else None
+    stats = worker.stats()
     grid = list(worker.grid_dims()) if not distributed else None
     worker.close()
 
@@ -493,6 +498,7 @@ def main():
             "repetitions": {"count": len(reps), "reported": "the repetition with the median time (each window on its own)",
                             "ms_per_step": [r["elapsed"] / args.steps * 1e3 for r in reps]},
             "roofline": roof,
+            "graph_replay": bool(args.graph),
             "step_traffic": None if distributed else step_traffic(
                 load_window_counters(cfg_name, args.dist, args.warmup, args.steps), elapsed / args.steps * 1e3),
             "kernel_ms": breakdown,
@@ -508,9 +514,9 @@ def main():
             out["with_readback"] = with_readback
         if transport is not None:
             out["config"]["transport"] = type(transport).__name__
+        out["stats"] = stats
         if grid is not None:
             out["config"]["grid_cells"] = grid
-            out["stats"] = stats
         if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(pos, params, args.cpu_steps)
         else:

@@ -112,6 +112,14 @@ typedef struct ws_device_cfg {
  * default hardware v_sqrt_f32 / v_rcp_f32 forms (1 ULP each; x / y evaluated as x * rcp(y)), which stay inside the
  * accuracy WGSL grants the reference's own GPU execution (x / y: 2.5 ULP).  ~2x slower density/force kernels. */
 #define WS_FLAG_IEEE_DIVISION 4u
+/* Replay the step from a captured hipGraph instead of launching its kernels one by one: what the reference does with
+ * its pass graph (built once in FluidWorker::build, replayed by AppComputeWorker::run every frame,
+ * src/fluid_compute.rs:309-363,:396).  The step is captured on the first steady-state ws_step (and again when a slab's
+ * launch bound moves by more than 65 536 particles); results are identical to direct launches.  If the step cannot be
+ * captured (a host transport that synchronises the stream), the handle falls back to direct launches
+ * (ws_last_error says so once).  Ignores WS_FLAG_PROFILE.  Off by default: direct launches already pipeline on the
+ * stream and measure as fast on one MI355X. */
+#define WS_FLAG_GRAPH 8u
 
 typedef struct ws_handle ws_handle;
 
@@ -248,6 +256,17 @@ const char *ws_rccl_last_error(void);
  * communicator ever sees operations from two streams; 1 = WS_RCCL_SINGLE_COMM=1 or an RCCL without ncclCommSplit. */
 uint32_t ws_rccl_transport_communicators(const ws_transport *t);
 
+/* A ws_transport for several slabs inside ONE process, one host thread per slab (one GPU or several): plain
+ * device-to-device copies between the slabs' message buffers with a host rendezvous.  For hosts that drive all their GPUs
+ * from one process, and for exercising the whole slab protocol on a one-GPU box (host/frame_loop.cpp, tests).  Every
+ * call synchronises its stream: correct, not fast, and not capturable (WS_FLAG_GRAPH falls back to direct launches).  A
+ * rank that is left alone in a collective for 300 s breaks the hub (every call then fails) instead of hanging.  The hub
+ * must outlive its transports, a transport the handle created with it. */
+ws_status ws_local_hub_create(uint32_t world_size, void **hub_out);
+void ws_local_hub_destroy(void *hub);
+ws_status ws_local_transport_create(void *hub, uint32_t rank, ws_transport *out);
+void ws_local_transport_destroy(ws_transport *t);
+
 /* Host-only: which slab owns each position (by the x cell of floor(x / h) in the global grid, equal
  * cell-count cuts S_r = r * nx / world_size).  out_rank holds n entries. */
 ws_status ws_slab_assign(const ws_params *params, const float *pos_xyz, uint32_t n, uint32_t world_size,
@@ -310,7 +329,8 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
 /* out[0] = cumulative particle-steps with more candidates than the accept mask holds (their waves took the full
  * sweep in the force kernel); out[1..3] = how many of the reference's cells (edge = smoothing radius) one cell of the
  * device grid spans along x, y, z -- 1 unless the reference-sized grid would exceed the cell budget (a small
- * smoothing radius in a big container), see ws_grid_dims; the rest reserved. */
+ * smoothing radius in a big container), see ws_grid_dims; out[4] = steps replayed from a captured hipGraph
+ * (WS_FLAG_GRAPH); the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

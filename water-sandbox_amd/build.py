@@ -7,7 +7,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwsfluid.so")
 
-SOURCES = ["ws_kernels.hip", "ws_api.cpp", "ws_rccl.cpp"]
+SOURCES = ["ws_kernels.hip", "ws_api.cpp", "ws_rccl.cpp", "ws_local.cpp"]
 HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
 # Test-only build of the same sources plus the reference-order validation mode (tests/refcheck/: a literal HIP
 # restatement of the reference's six WGSL passes and its host glue, used by the tests as a second, independent

@@ -21,6 +21,7 @@ thread_local std::string g_create_error;
 
 // ws_slab.inc
 void slab_free(ws_handle *h);
+void slab_drop_graphs(WsSlab *S);
 ws_status slab_step(ws_handle *h);
 ws_status slab_settle(ws_handle *h);
 ws_status slab_read_by_id(ws_handle *h, int kind, void *out);
@@ -205,7 +206,6 @@ ws_status alloc_grid(ws_handle *h)
     h->start = h->start_alloc + (4u - (uint32_t)d.guard % 4u) % 4u;
     HIP_TRY(h, hipMalloc(&h->bsum, (size_t)wsk_scan_state_words(d.ncells) * 4));
     HIP_TRY(h, hipMemsetAsync(h->bsum, 0, (size_t)wsk_scan_state_words(d.ncells) * 4, h->stream));  // same stream as its users
-    h->scan_launches = 0;
     // constant parts of cell_start: front guard = 0, [ncells] and the back guard = n
     HIP_TRY(h, hipMemsetAsync(h->start, 0, (size_t)d.guard * 4, h->stream));
     std::vector<uint32_t> tail((size_t)d.guard + 2, d.n);
@@ -397,7 +397,7 @@ void enqueue_step(ws_handle *h)
     {
         Prof p(h, WS_K_SCAN);
         // no fill cursors: particles are placed by the ranks they drew when they were binned
-        wsk_scan(s, h->count, h->start + d.guard, nullptr, h->bsum, &h->scan_launches, d.ncells, true, 0);
+        wsk_scan(s, h->count, h->start + d.guard, nullptr, h->bsum, d.ncells, true, 0);
     }
     {
         Prof p(h, WS_K_SCATTER);
@@ -497,8 +497,17 @@ ws_status upload_positions(ws_handle *h, const float *pos_xyz)
     return WS_OK;
 }
 
+// captured steps hold kernel arguments by value (WsDev) and array pointers: anything that changes either drops them
+void drop_graphs(ws_handle *h)
+{
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+    if (h->slab) slab_drop_graphs(h->slab);
+}
+
 void free_particle_arrays(ws_handle *h)
 {
+    drop_graphs(h);
     hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred); hipFree(h->cur.rank);
     hipFree(h->srt.pos); hipFree(h->srt.pv);
     hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
@@ -677,6 +686,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     h->n = n;
     h->params = *params;
     configure_kernels(h);
+    if (h->flags & WS_FLAG_GRAPH) h->flags &= ~(uint32_t)WS_FLAG_PROFILE;  // event brackets are not part of a captured step
 
     auto bail = [&](ws_status s) {
         g_create_error = h->err;
@@ -761,9 +771,39 @@ ws_status ws_step(ws_handle *h)
     if (h->slab) return slab_step(h);
     WS_REF_DISPATCH(h, ref_step(h));
     hipStream_t s = h->stream;
-    // (A hipGraph replay of this fixed 7-launch sequence was measured and is NOT faster than the direct
-    // launches, which already pipeline on the stream: C1 0.061 vs 0.055 ms/step, C2 0.107 vs 0.100, C3 equal.)
     bound_pending(h);
+    // WS_FLAG_GRAPH: the five launches as one captured graph (the reference replays its pass graph the same way,
+    // src/fluid_compute.rs:309-363,:396).  Off by default: measured no faster than the direct launches, which already
+    // pipeline on the stream (round 1: C1 0.061 vs 0.055 ms/step, C2 0.107 vs 0.100, C3 equal; round 3: DESIGN.md).
+    // The first step after an upload takes the caller's predicted positions (k_reorder<false>) and is launched directly.
+    if ((h->flags & WS_FLAG_GRAPH) && !h->graph_failed && h->pred_stale) {
+        if (!h->graph_exec) {
+            hipGraph_t gr = nullptr;
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                enqueue_step(h);
+                e = hipStreamEndCapture(s, &gr);
+                if (e == hipSuccess) e = hipGraphInstantiate(&h->graph_exec, gr, nullptr, nullptr, 0);
+                if (gr) hipGraphDestroy(gr);
+            }
+            if (e != hipSuccess || !h->graph_exec) {
+                (void)hipGetLastError();
+                h->graph_failed = true;
+                h->graph_exec = nullptr;
+                h->err = std::string("WS_FLAG_GRAPH: capture failed (") + hipGetErrorName(e) + "), using direct launches";
+            }
+        }
+        if (h->graph_exec) {
+            HIP_TRY(h, hipGraphLaunch(h->graph_exec, s));
+            h->pred_stale = true;
+            h->accel_stale = true;
+            h->graph_steps++;
+            HIP_TRY(h, hipEventRecord(h->done, s));
+            h->done_recorded = true;
+            h->steps++;
+            return WS_OK;
+        }
+    }
     enqueue_step(h);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));
@@ -810,7 +850,7 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
     if (st) return st;
     HIP_TRY(h, hipSetDevice(h->device));
     WsDev nd;
-    st = derive_dev(h, *params, h->n, &nd);
+    st = derive_dev(h, *params, h->slab ? h->slab->n_global : h->n, &nd);  // (the cell budget follows the GLOBAL count)
     if (st) return st;
     const WsDev &od = h->dev;
     bool regrid = memcmp(nd.org, od.org, sizeof nd.org) || memcmp(nd.dim, od.dim, sizeof nd.dim) || nd.h != od.h;
@@ -839,9 +879,12 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
     }
     h->params = *params;
     if (!regrid) {
+        // (update() pushes the same parameters every frame, src/fluid_compute.rs:479-481: a captured step survives that)
+        if (memcmp(&h->dev, &nd, sizeof nd) != 0) drop_graphs(h);
         h->dev = nd;  // by-value kernel argument: picked up by the next ws_step
         return WS_OK;
     }
+    drop_graphs(h);
     // cell size or container changed: rebuild the grid tables and re-bin the current state
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->dev = nd;
@@ -1051,7 +1094,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         // the predicted positions the last step started from live in the sorted copy
         wsk_view_keys(s, h->dev, h->srt, h->v_keys, h->v_count);
     }
-    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, &h->v_scan_launches, n, false, 0);
+    wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, n, false, 0);
     wsk_scatter(s, keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n, nullptr);
     wsk_view_fix(s, h->v_tmp, keys, h->v_start, h->v_perm, n);
     wsk_view_offsets(s, h->v_start, h->v_off, n);
@@ -1102,6 +1145,7 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
     if (st) return st;
     HIP_TRY(h, hipMemcpy(out, h->stats, 64, hipMemcpyDeviceToHost));
     for (int c = 0; c < 3; c++) out[1 + c] = (uint32_t)h->dev.cm[c];  // reference cells merged per grid cell (host-side)
+    out[4] = (uint32_t)(h->slab ? h->slab->graph_steps : h->graph_steps);  // steps replayed from a captured graph
     return WS_OK;
 }
 

@@ -71,6 +71,9 @@ enum {
     DY_LEFT,         // cumulative: particles that left / arrived
     DY_ARRIVED,
     DY_FAR,          // cumulative: leavers that took the all-gathered route (crossed more than one slab in a step)
+    DY_STEP,         // steps whose migration has run since the handle was created / reset (k_migrate_fill counts): the
+                     // stamp of every message and the slot of the status ring come from here, not from the host, so a
+                     // captured graph of the step replays unchanged
     WS_DYN_WORDS = 16
 };
 enum {
@@ -170,7 +173,6 @@ struct ws_handle {
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
     uint32_t *start_alloc = nullptr;  // its allocation (start sits 0..3 words in: see alloc_grid)
     uint32_t *bsum = nullptr;     // scan state (ticket + tile descriptors), zeroed at allocation
-    uint32_t scan_launches = 0, v_scan_launches = 0;  // scans run on bsum / v_bsum since they were zeroed
     WsMask mask = {nullptr, 0};   // accept masks (listed variant)
     bool ieee = false;            // WS_FLAG_IEEE_DIVISION: correctly rounded sqrt / division in the pair terms
     uint32_t *stats = nullptr;    // device counters: [0] particle-steps with more candidates than the mask holds
@@ -203,6 +205,11 @@ struct ws_handle {
     WsRef ref;
 #endif
 
+    // WS_FLAG_GRAPH on a single-GPU handle: the captured steady-state step
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_failed = false;
+    uint64_t graph_steps = 0;
+
     // slab (multi-GPU) state; slab == nullptr on a single-GPU handle
     bool accel_stale = false;  // accel[] is behind the last step (computed on demand: refresh_accel)
     bool pred_stale = false;  // cur.pred is behind cur.pos / cur.vel (the step loop does not store it: k_reorder)
@@ -212,6 +219,10 @@ struct ws_handle {
     std::string err;
 };
 
+struct WsGraphEntry {
+    uint32_t n_bound = 0;
+    hipGraphExec_t exec = nullptr;
+};
 struct WsSlab {
     ws_transport tr{};
     uint32_t rank = 0, world = 1;
@@ -253,6 +264,12 @@ struct WsSlab {
     hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr, ev_filled = nullptr;
     bool overlap = true;              // WS_SLAB_OVERLAP=0 turns it off
     bool last_split = false;          // the last step ran K4 / K5 as early + late launches (refresh_accel repeats that)
+    // WS_FLAG_GRAPH: captured steps, one per (quantised) launch bound
+    std::vector<struct WsGraphEntry> graphs;
+    bool graph_failed = false;        // the step could not be captured (transport / runtime): direct launches
+    bool capturing = false;           // a capture is being recorded: a transport refusal is not a communication failure
+    uint64_t graph_steps = 0;         // steps replayed from a graph
+    hipEvent_t ev_copied = nullptr;
     // cumulative statistics (refreshed by ws_slab_read_particles)
     uint64_t migrated_out = 0;
 };
@@ -263,8 +280,8 @@ void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur,
 void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count, uint32_t *rank);
 void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const float4 *pos_with_id,
                const uint32_t *start, uint32_t *slot_tmp, uint32_t *id_tmp);
-void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t *launches,
-              uint32_t nitems, bool zero_count, uint32_t base);
+void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t nitems,
+              bool zero_count, uint32_t base);
 uint32_t wsk_scan_state_words(uint32_t nitems);
 void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
                  uint32_t *id_tmp, uint32_t n, const uint32_t *n_dev);
@@ -295,13 +312,12 @@ void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cu
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
-                      uint32_t *count, uint32_t *status, uint32_t hole_cap, uint32_t *sendL, uint32_t *sendR,
-                      uint32_t *far_send, uint32_t step);
+                      uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
+                      uint32_t *sendR, uint32_t *far_send);
 void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
-                   uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities, uint32_t step);
+                   uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities);
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,
-                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities,
-                     uint32_t step);
+                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities);
 void wsk_gather_slab(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                      ws_particle80 *out, uint32_t *ids);
 void wsk_upload_positions_ids(hipStream_t s, const float *xyz_dev, const uint32_t *ids_dev, WsSoA cur, uint32_t n);

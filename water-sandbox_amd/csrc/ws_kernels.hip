@@ -253,8 +253,9 @@ __device__ __forceinline__ uint32_t wave_run_atomic_inc(uint32_t *__restrict__ t
 // One-pass exclusive scan (decoupled look-back): tile t publishes its aggregate, then walks back over its
 // predecessors' descriptors until it meets an inclusive prefix, and publishes its own.  Tiles take their
 // index from a ticket counter, so every predecessor of a running tile is itself running or done: the
-// wait cannot deadlock.  state[0] = ticket counter, never reset: launch number `epoch` (counted per buffer
-// by the owner, from 1) hands out tickets epoch * ntiles ... in modular arithmetic.  64-bit descriptors from
+// wait cannot deadlock.  state[0..1] = a 64-bit ticket counter, never reset: every launch on a buffer draws exactly
+// ntiles tickets, so ticket / ntiles numbers the launches (the `epoch`) and ticket % ntiles the tiles -- nothing of
+// this comes from the host, so a captured hipGraph of the step replays it unchanged.  64-bit descriptors from
 // state[2]: hi = epoch << 2 | status (1 = aggregate, 2 = inclusive prefix), lo = value.  A descriptor of
 // another epoch reads as "not yet written", so nothing is cleared between launches.  A descriptor carries its
 // whole message in one 64-bit word, so relaxed device-scope atomics suffice (acquire / release at agent scope
@@ -262,15 +263,16 @@ __device__ __forceinline__ uint32_t wave_run_atomic_inc(uint32_t *__restrict__ t
 template <bool ZERO>
 __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count, uint32_t nitems,
                                                    uint32_t *__restrict__ state, uint32_t *__restrict__ start,
-                                                   uint32_t *__restrict__ cursor, uint32_t start_offset, uint32_t epoch,
-                                                   uint32_t ntiles)
+                                                   uint32_t *__restrict__ cursor, uint32_t start_offset, uint32_t ntiles)
 {
-    __shared__ uint32_t s_tile, s_prefix;
+    __shared__ uint32_t s_tile, s_epoch, s_prefix;
     if (threadIdx.x == 0) {
-        s_tile = atomicAdd(&state[0], 1u) - (epoch - 1u) * ntiles;
+        const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long *>(state), 1ull);
+        s_tile = (uint32_t)(ticket % ntiles);
+        s_epoch = (uint32_t)(ticket / ntiles) + 1u;  // modulo 2^32: only ever compared for equality with its neighbours
     }
     __syncthreads();
-    const uint32_t tile = s_tile;
+    const uint32_t tile = s_tile, epoch = s_epoch;
     // A tile is WS_SCAN_ITEMS / 4 chunks of WS_BLOCK uint4: thread t owns uint4 number t of every chunk, so
     // every load and store of the tile is a coalesced 16 B per lane.
     constexpr int Q = WS_SCAN_ITEMS / 4;
@@ -380,17 +382,16 @@ uint32_t wsk_scan_state_words(uint32_t nitems) { return 2u + 2u * cdiv(nitems, W
 
 // start_body points at the first real entry (after the guard); entry [nitems] and the
 // guards are constant and written once by the host.
-void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state,
-              uint32_t *launches, uint32_t nitems, bool zero_count, uint32_t base)
+void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t nitems,
+              bool zero_count, uint32_t base)
 {
-    const uint32_t epoch = ++*launches;  // per state buffer, from 1
     const uint32_t ntiles = cdiv(nitems, WS_SCAN_TILE);
     if (zero_count)
         hipLaunchKernelGGL(k_scan<true>, dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor,
-                           base, epoch, ntiles);
+                           base, ntiles);
     else
         hipLaunchKernelGGL(k_scan<false>, dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor,
-                           base, epoch, ntiles);
+                           base, ntiles);
 }
 
 // ---------------------------------------------------------------------------------
@@ -682,6 +683,9 @@ __device__ __forceinline__ void density_store(float density, float near_density,
 {
     density = density + 0.00001f;  // DENSITY_PADDING, simulation.wgsl:4,187-188
     near_density = near_density + 0.00001f;
+#ifdef ND_ABLATE_DENSITY_STORE  // ablation (wrong results): what do the two 4-byte patches cost?  one store per 64 particles instead
+    if ((i & 63u) != 0u) return;
+#endif
     srt.pred(i).w = density;
     srt.vel(i).w = near_density;
 }
@@ -887,8 +891,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 // bits of its mask, maps the bit number to the neighbour's index through a 9-entry per-lane run table
 // in LDS, gathers {pred, density} and {vel, near density} (2 x 16 B, issued one neighbour ahead) and
 // does the pair arithmetic -- then integrates and bins for the next step.
-// A particle with more than 32 * ND_MASK_WORDS candidates keeps no mask; a wave that holds such a
-// particle takes the simple sweep in K5 instead (same visit order, same operations).
+// A particle with more than 32 * ND_MASK_WORDS candidates keeps no mask and takes the simple sweep in K5 instead
+// (same visit order, same operations); the other lanes of its wave still walk their masks.
 // Visit order = (dx, dy, z, slot) ascending in every variant: all of them produce the same sums
 // bit for bit.
 // ---------------------------------------------------------------------------------
@@ -1031,7 +1035,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         acc32 |= bits << pos;
         pos += nvalid;
         if (pos >= 32u) {  // pos was >= 28, so the shift below is by 1..4
+#ifndef ND_ABLATE_MASK_STORE  // ablation (wrong results): what do the accept-mask stores cost?
             if (word < ND_MASK_WORDS) mrow[(size_t)word * mask.stride] = acc32;
+#endif
             pos -= 32u;
             acc32 = bits >> (nvalid - pos);  // the bits that spilled over: the trip's last `pos` ones
             word++;
@@ -1120,12 +1126,17 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         t_end[9 * NF_P + threadIdx.x] = 0xFFFFFFFFu;
         if (!valid) total = 0;
     }
-    if (!__ballot(total > 32u * ND_MASK_WORDS)) {
+    // A particle with more candidates than the accept mask holds (> 2 048: a cell column of the settled floor layer in the
+    // tall containers) has no mask and takes the plain sweep -- that particle alone: the other lanes of its wave walk
+    // their masks (with the per-lane iterator: the word-synchronous walk needs the whole wave).
+    const bool over = total > 32u * ND_MASK_WORDS;
+    const bool any_over = __ballot(over) != 0ull;
+    if (!over) {
         const uint32_t *mrow = mask.words + (iv - d.base);
         const uint32_t nwords = (total + 31u) >> 5;
         uint32_t run = 0, end_r = t_end[threadIdx.x], delta_r = t_delta[threadIdx.x];
         const uint32_t self_s = i - t_delta[4 * NF_P + threadIdx.x];  // own candidate number (own cell = run 4)
-      if (!__ballot(nwords > (uint32_t)NF_WORDSYNC_MAX)) {
+      if (!any_over && !__ballot(nwords > (uint32_t)NF_WORDSYNC_MAX)) {
         // A wave whose particles all have few candidates (the sparse state: 1-2 mask words each) walks its 64 masks
         // WORD BY WORD, all lanes on the same word number: inside a word every lane takes its set bits one per
         // trip (the neighbours in visit order).  The rare work -- next word, dropping the particle's own bit
@@ -1180,6 +1191,12 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         // run.  The two rare steps -- next mask word, next run -- are short and independent, so a wave in which some
         // lane takes one of them on almost every trip (9 words and 9 runs per lane in the dense state) pays ~15
         // instructions for it, not the ~40 of a combined word-and-run segment computation.
+#ifdef NF_PREFETCH_RUN
+        // The next run's table entries are fetched from LDS when the current run is entered, so that a run switch is
+        // two register moves and never waits for LDS (some lane of a dense wave switches runs on nearly every trip,
+        // and the whole wave would wait for its LDS round trip).
+        uint32_t end_n = t_end[NF_P + threadIdx.x], delta_n = t_delta[NF_P + threadIdx.x];
+#endif
         auto next = [&](uint32_t &j) -> bool {
             while (rest == 0u) {
                 if (widx >= nwords) return false;
@@ -1191,11 +1208,21 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
             }
             const uint32_t sc = wbase + (uint32_t)__ffs((int)rest) - 1u;
             rest &= rest - 1u;
+#ifdef NF_PREFETCH_RUN
+            while (sc >= end_r) {
+                run++;
+                end_r = end_n;
+                delta_r = delta_n;
+                end_n = t_end[min(run + 1u, 9u) * NF_P + threadIdx.x];
+                delta_n = t_delta[min(run + 1u, 8u) * NF_P + threadIdx.x];
+            }
+#else
             while (sc >= end_r) {
                 run++;
                 end_r = t_end[run * NF_P + threadIdx.x];
                 delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
             }
+#endif
             j = sc + delta_r;
             return true;
         };
@@ -1477,13 +1504,15 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
                                                                  const uint32_t *__restrict__ far_all, uint32_t far_cap,
                                                                  uint32_t *__restrict__ tgt, uint32_t *__restrict__ src,
                                                                  WsSoA cur, uint32_t *__restrict__ cid_cur,
-                                                                 uint32_t *__restrict__ count, uint32_t *__restrict__ status,
+                                                                 uint32_t *__restrict__ count,
+                                                                 uint32_t *__restrict__ status_ring, uint32_t status_slots,
                                                                  uint32_t hole_cap, uint32_t *__restrict__ sendL,
-                                                                 uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send,
-                                                                 uint32_t step)
+                                                                 uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send)
 {
     __shared__ uint32_t s_far, s_ntgt, s_nsrc, s_nnew, s_nold, s_arr;
     const uint32_t tid = threadIdx.x;
+    const uint32_t step = dyn[DY_STEP];  // (nobody writes it before the last barrier below)
+    uint32_t *status = status_ring + (size_t)(step % status_slots) * world * WS_HDR_WORDS;
     const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;  // words per rank in the gathered far buffer
     const bool left = me > 0, right = me + 1 < world;
     if (tid == 0) {
@@ -1580,6 +1609,7 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
     __syncthreads();
     if (tid == 0) {
         dyn[DY_N] = n_new;
+        dyn[DY_STEP] = step + 1u;
         dyn[DY_NHOLE] = 0;
         dyn[DY_ARRIVED] += s_arr;
         dyn[DY_LEFT] += leave;
@@ -1600,11 +1630,12 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
-                      uint32_t *count, uint32_t *status, uint32_t hole_cap, uint32_t *sendL, uint32_t *sendR,
-                      uint32_t *far_send, uint32_t step)
+                      uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
+                      uint32_t *sendR, uint32_t *far_send)
 {
     hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
-                       mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status, hole_cap, sendL, sendR, far_send, step);
+                       mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status_ring, status_slots, hole_cap, sendL, sendR,
+                       far_send);
 }
 
 // Halo messages.  A: [header | cell-start slice of the boundary layer (rowy + 1 words, padded to 4) | its 32-byte
@@ -1615,7 +1646,7 @@ __device__ __forceinline__ uint32_t halo_slice_words(uint32_t rowy) { return (ro
 __global__ void __launch_bounds__(WS_BLOCK) k_halo_pack(WsDev d, const uint32_t *__restrict__ start, WsSorted srt,
                                                         uint32_t *__restrict__ dyn, uint32_t rowy, uint32_t halo_cap,
                                                         uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
-                                                        int densities, uint32_t step)
+                                                        int densities)
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     const uint32_t side = blockIdx.y;  // 0: the left-going layer (1), 1: the right-going layer (nxl - 2)
@@ -1632,7 +1663,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_pack(WsDev d, const uint32_t 
         msg[0] = cnt;
         msg[1] = dyn[DY_ERR];
         msg[2] = dyn[DY_N];
-        msg[3] = step;
+        msg[3] = dyn[DY_STEP];  // this step's migration has run on both ends: the same number on both
     }
     if (t <= rowy) msg[WS_HDR_WORDS + t] = start[first + t];
     if (t < cnt) {
@@ -1643,11 +1674,11 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_pack(WsDev d, const uint32_t 
 }
 
 void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
-                   uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities, uint32_t step)
+                   uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities)
 {
     const uint32_t work = densities ? halo_cap : max(halo_cap, rowy + 1u);
     hipLaunchKernelGGL(k_halo_pack, dim3(cdiv(work, WS_BLOCK), 2), dim3(WS_BLOCK), 0, s, d, start, srt, dyn, rowy, halo_cap,
-                       sendL, sendR, densities ? 1 : 0, step);
+                       sendL, sendR, densities ? 1 : 0);
 }
 
 // After halo A: the ghost records into [base - gL, base) and [base + n, base + n + gR), their planar copy for K4,
@@ -1658,7 +1689,7 @@ void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorte
 __global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__restrict__ start, WsSorted srt, WsXYZ sxyz,
                                                           uint32_t *__restrict__ dyn, uint32_t rowy, uint32_t nxl,
                                                           uint32_t ghost_cap, const uint32_t *__restrict__ recvL,
-                                                          const uint32_t *__restrict__ recvR, int densities, uint32_t step)
+                                                          const uint32_t *__restrict__ recvR, int densities)
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     const uint32_t side = blockIdx.y;
@@ -1680,7 +1711,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__r
         if (t == 0) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_GHOSTS);
         g = ghost_cap;
     }
-    if (t == 0 && have && msg[3] != step) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);  // another step's halo (see k_migrate_fill)
+    if (t == 0 && have && msg[3] != dyn[DY_STEP]) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);  // another step's halo (see k_migrate_fill)
     if (t == 0) dyn[side ? DY_GR : DY_GL] = g;
     const uint32_t *slice = msg + WS_HDR_WORDS;
     const uint32_t first_slot = side ? base + n : base - g;
@@ -1712,12 +1743,11 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_unpack(WsDev d, uint32_t *__r
 }
 
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,
-                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities,
-                     uint32_t step)
+                     uint32_t nxl, uint32_t ghost_cap, const uint32_t *recvL, const uint32_t *recvR, bool densities)
 {
     const uint32_t work = densities ? ghost_cap : max(ghost_cap, rowy + (uint32_t)d.guard + 2u);
     hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(work, WS_BLOCK), 2), dim3(WS_BLOCK), 0, s, d, start, srt, sxyz, dyn, rowy, nxl,
-                       ghost_cap, recvL, recvR, densities ? 1 : 0, step);
+                       ghost_cap, recvL, recvR, densities ? 1 : 0);
 }
 
 // Slab readback: owned particles (state of the last step, sorted order) with their ids.

@@ -30,6 +30,7 @@ assert PARTICLE_DTYPE.itemsize == 80
 WS_FLAG_PROFILE = 1
 WS_FLAG_REFERENCE_ORDER = 2
 WS_FLAG_IEEE_DIVISION = 4
+WS_FLAG_GRAPH = 8
 KERNEL_IDS = {"cell_scan": 0, "cell_scatter": 1, "reorder": 2, "density": 3, "force_integrate_bin": 4, "bin": 5}
 
 # every symbol include/wsfluid.h declares (tests check the library exports all of them)
@@ -38,7 +39,8 @@ ABI_SYMBOLS = [
     "ws_bit_sorter_stage_count", "ws_status_string", "ws_abi_version", "ws_create", "ws_destroy",
     "ws_step", "ws_ready", "ws_sync", "ws_set_params", "ws_read_positions", "ws_read_particles",
     "ws_reset", "ws_write_particles", "ws_pin_host_buffer", "ws_unpin_host_buffer", "ws_read_speeds", "ws_read_positions_begin", "ws_read_positions_end", "ws_slab_counters", "ws_rccl_unique_id", "ws_rccl_transport_create",
-    "ws_rccl_transport_destroy", "ws_rccl_last_error", "ws_rccl_transport_communicators", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
+    "ws_rccl_transport_destroy", "ws_rccl_last_error", "ws_rccl_transport_communicators",
+    "ws_local_hub_create", "ws_local_hub_destroy", "ws_local_transport_create", "ws_local_transport_destroy", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
     "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
     "ws_grid_dims", "ws_read_stats", "ws_slab_assign", "ws_slab_create", "ws_slab_read_particles",
 ]
@@ -207,7 +209,7 @@ class FluidWorker:
     returns the 80-byte records in original-id order."""
 
     def __init__(self, positions, params=None, device=0, profile=False, reference_order=False, ieee_division=False,
-                 library=None):
+                 library=None, graph=False):
         self._L = library if library is not None else load_library()
         self._h = C.c_void_p()
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -216,7 +218,7 @@ class FluidWorker:
         cfg = WsDeviceCfg()
         cfg.device = device
         cfg.flags = ((WS_FLAG_PROFILE if profile else 0) | (WS_FLAG_REFERENCE_ORDER if reference_order else 0)
-                     | (WS_FLAG_IEEE_DIVISION if ieee_division else 0))
+                     | (WS_FLAG_IEEE_DIVISION if ieee_division else 0) | (WS_FLAG_GRAPH if graph else 0))
         st = self._L.ws_create(C.byref(self.params), positions.ctypes.data, self.n, C.byref(cfg), C.byref(self._h))
         if st != 0:
             raise WsError(st, (self._L.ws_last_error(None) or b"").decode())
@@ -330,7 +332,7 @@ class FluidWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4])}
+        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4])}
 
     def profile(self):
         """{kernel name: (total_ms, launches)} since the last profile_reset (needs profile=True)."""

@@ -281,7 +281,7 @@ class SlabWorker:
     """One x-slab of the domain on one GPU (ws_slab_create / ws_step / ws_slab_read_particles)."""
 
     def __init__(self, positions, ids, n_global, params, rank, world, transport, device=0, stream=None, profile=False,
-                 capacity=0, ghost_capacity=0, ieee_division=False):
+                 capacity=0, ghost_capacity=0, ieee_division=False, graph=False):
         L = self._L = fluid.load_library()
         L.ws_slab_create.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(fluid.WsDeviceCfg), C.POINTER(WsTransport), C.POINTER(C.c_void_p)]
@@ -294,7 +294,8 @@ class SlabWorker:
         assert positions.shape[0] == ids.shape[0]
         cfg = fluid.WsDeviceCfg()
         cfg.device, cfg.rank, cfg.world_size = device, rank, world
-        cfg.flags = (fluid.WS_FLAG_PROFILE if profile else 0) | (fluid.WS_FLAG_IEEE_DIVISION if ieee_division else 0)
+        cfg.flags = ((fluid.WS_FLAG_PROFILE if profile else 0) | (fluid.WS_FLAG_IEEE_DIVISION if ieee_division else 0)
+                     | (fluid.WS_FLAG_GRAPH if graph else 0))
         cfg.capacity, cfg.ghost_capacity = capacity, ghost_capacity
         cfg.stream = stream
         self.params = params
@@ -377,7 +378,7 @@ class SlabWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4])}
+        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4])}
 
     def counters(self):
         """Migration counters since creation (ws_slab_counters): owned now, left, arrived, left by the far route."""
