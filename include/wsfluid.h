@@ -115,9 +115,9 @@ typedef struct ws_device_cfg {
 /* Replay the step from a captured hipGraph instead of launching its kernels one by one: what the reference does with
  * its pass graph (built once in FluidWorker::build, replayed by AppComputeWorker::run every frame,
  * src/fluid_compute.rs:309-363,:396).  The step is captured on the first steady-state ws_step (and again when a slab's
- * launch bound moves by more than 65 536 particles); results are identical to direct launches.  If the step cannot be
- * captured (a host transport that synchronises the stream), the handle falls back to direct launches
- * (ws_last_error says so once).  Ignores WS_FLAG_PROFILE.  Off by default: direct launches already pipeline on the
+ * launch bound moves by more than 65 536 particles); results are identical to direct launches.  On slab handles the
+ * flag is honoured with the library's own RCCL transport (and for a world of one); a host-supplied transport may
+ * synchronise the stream inside its callbacks, so such handles keep launching directly.  Ignores WS_FLAG_PROFILE.  Off by default: direct launches already pipeline on the
  * stream and measure as fast on one MI355X. */
 #define WS_FLAG_GRAPH 8u
 
@@ -279,6 +279,14 @@ ws_status ws_slab_create(const ws_params *params, const float *pos_xyz, const ui
 /* The particles this slab owns now (count varies with migration): up to cap records and their global
  * ids, in no particular order; *n_out = number owned.  Waits for enqueued steps. */
 ws_status ws_slab_read_particles(ws_handle *h, ws_particle80 *out, uint32_t *out_ids, uint32_t cap, uint32_t *n_out);
+/* COLLECTIVE re-cut: move the slab boundaries so that every slab owns about n_global / world_size particles again (cuts
+ * stay on cell-layer boundaries; every slab keeps at least one layer).  ws_slab_assign's cuts give every slab the same
+ * number of cell LAYERS, which is balanced while the fluid is spread evenly along x; a gravity with an x component
+ * (the HUD can set any, src/hud.rs:151-162) piles it up at one end until that slab's capacity overruns.  A host that sees
+ * the owned counts drift apart (ws_slab_counters / ws_num_particles) calls this on every rank at the same point; the
+ * particles are redistributed like on a re-grid and the run continues bit-identically to a single handle.  Cheap
+ * when nothing needs to move (one gather; every rank decides alike). */
+ws_status ws_slab_rebalance(ws_handle *h);
 /* Migration counters of this slab since it was created, as of the last migration that has run (waits for enqueued
  * steps): out[0] = particles owned now, out[1] = particles that left, out[2] = particles that arrived, out[3] = of
  * those that left, the ones that crossed more than one slab in a step (the all-gathered route).  The reference is a

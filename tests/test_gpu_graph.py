@@ -69,9 +69,10 @@ def test_slab_step_graph_replay_through_the_native_rccl_transport(ws):
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
-def test_a_transport_that_cannot_be_captured_falls_back_to_direct_launches(ws):
-    """The tests' loopback transport synchronises the stream inside its callbacks: the capture fails, the handle says
-    so and goes on with direct launches -- same results, nobody hangs."""
+def test_a_host_transport_is_never_captured(ws):
+    """A host-supplied transport (here the tests' loopback, which synchronises the stream and meets the other slabs on a
+    host barrier inside its callbacks) cannot be recorded into a graph: such handles ignore the flag and launch
+    directly -- same results, nobody hangs."""
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(32768, 5, list(params.ext_min), list(params.ext_max))
     w = ws.FluidWorker(pos, params)

@@ -8,12 +8,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_frame_loop_runs_reset_and_param_change():
+def _exe():
     exe = os.path.join(ROOT, "water-sandbox_amd", "host", "frame_loop")
     if not os.path.exists(exe):
         import runpy
 
         runpy.run_path(os.path.join(ROOT, "water-sandbox_amd", "host", "build_host.py"), run_name="__main__")
+    return exe
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_cpp_frame_loop_on_slabs_is_bit_identical_to_the_single_handle(world):
+    """host/frame_loop.cpp --slabs W: the reference's frame order (update -> despawn -> run, src/fluid_compute.rs:468-525)
+    from C++ on one handle and on W x-slabs (one host thread each, the library's in-process transport), with two
+    smoothing-radius changes, a reset and a gravity change on the way: every frame's id-ordered positions equal."""
+    out = subprocess.run([_exe(), "--slabs", str(world), "50"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bit-identical to the single handle on every rank" in out.stdout
+
+
+def test_frame_loop_runs_reset_and_param_change():
+    exe = _exe()
     out = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "60 frames, 65536 particles" in out.stdout

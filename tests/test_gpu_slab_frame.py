@@ -163,3 +163,36 @@ def test_particles_that_overshoot_the_padding_with_halo_overlap_on(ws, monkeypat
     assert sum(owned) == pos.shape[0]
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_rebalance_moves_the_cuts_where_static_cuts_overrun(ws):
+    """Equal-layer cuts are balanced only while the fluid is spread evenly along x.  With gravity tilted towards +x the
+    last of three slabs fills up until its capacity overruns (ws_step fails on every rank); the same run with a
+    collective ws_slab_rebalance every 8 steps keeps every slab near n / 3, never overruns, and still reproduces the single
+    handle bit for bit."""
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
+    world, steps, cap = 3, 96, 65536 // 3 + 6000
+    errs = ws.slab.run_loopback(pos, params, world, steps, collect_errors=True, capacity=cap)
+    assert sorted(errs) == list(range(world)), "static cuts were expected to overrun this capacity: %r" % (errs,)
+    w = ws.FluidWorker(pos, params)
+    w.run(steps)
+    want = w.read_vec("particles")
+    w.close()
+
+    def program(s, rank):
+        owned = []
+        for k in range(steps // 8):
+            s.run(8)
+            s.rebalance()
+            owned.append(s.num_owned())
+        return s.read_vec("particles"), owned
+
+    results = ws.slab.run_loopback_program(pos, params, world, program, capacity=cap)
+    for r, (got, owned) in enumerate(results):
+        assert max(owned) <= cap
+        for f in want.dtype.names:
+            assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), (f, r)
+    final = [results[r][1][-1] for r in range(world)]
+    assert sum(final) == pos.shape[0]
+    assert max(final) - min(final) < 65536 // 3 // 2, "not balanced: %r" % (final,)

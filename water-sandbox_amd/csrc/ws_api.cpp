@@ -28,7 +28,7 @@ ws_status slab_read_by_id(ws_handle *h, int kind, void *out);
 ws_status slab_gather_by_id(ws_handle *h, int kind);
 ws_status slab_reset(ws_handle *h, const float *pos_xyz);
 ws_status slab_write_particles(ws_handle *h, const ws_particle80 *in);
-ws_status slab_regrid(ws_handle *h, const ws_params *params);
+ws_status slab_regrid(ws_handle *h, const ws_params *params, bool rebalance);
 
 ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipSuccess)
 {
@@ -865,7 +865,7 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
     }
     WS_REF_DISPATCH(h, ref_set_params(h, params, nd));
     // (slab handles: COLLECTIVE when the cell size or the container changes -- every rank must make the same call)
-    if (h->slab && regrid) return slab_regrid(h, params);
+    if (h->slab && regrid) return slab_regrid(h, params, false);
     // The last step's accelerations are computed on demand from the state and the parameters that step used: if a
     // parameter they depend on changes (or the grid goes away), compute them now.  (A host that pushes unchanged
     // parameters every frame, as the reference's update() does, pays nothing.)

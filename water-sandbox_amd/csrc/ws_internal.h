@@ -328,6 +328,8 @@ void wsk_slab_pack(hipStream_t s, const WsDev &d, int kind, WsSoA cur, WsSorted 
                    uint32_t *out);
 void wsk_slab_unpack_by_id(hipStream_t s, const uint32_t *all, const uint32_t *cnt, uint32_t world, uint32_t max_n,
                            size_t stride_words, uint32_t pw, uint32_t n_global, uint32_t *out);
+void wsk_slab_layer_hist(hipStream_t s, const WsDev &d, const uint32_t *all, const uint32_t *cnt, uint32_t world, uint32_t max_n,
+                         size_t stride_words, uint32_t *hist);
 void wsk_slab_select(hipStream_t s, const WsDev &d, int src, const uint32_t *cuts, uint32_t world, uint32_t me,
                      const void *chunk, uint32_t id0, uint32_t m, const uint32_t *cnt, size_t stride_words, WsSoA cur,
                      uint32_t cap, uint32_t *dyn);

@@ -1009,6 +1009,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     const bool valid = v < sp.len;
     const uint32_t iv = span_at(sp, valid ? v : sp.len - 1u), i = iv;  // lanes past the end shadow the last particle
     const float4 o = make_float4(sxyz.x[iv], sxyz.y[iv], sxyz.z[iv], 0.f);  // the planar copy: coalesced, same bits
+#ifdef ND_FULL_STORE
+    const float4 own_vel = srt.vel(iv);
+#endif
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
     float density = 0.f, near_density = 0.f;
@@ -1068,7 +1071,13 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     if (valid) {
         if (pos && word < ND_MASK_WORDS) mrow[(size_t)word * mask.stride] = acc32;
         if (32u * word + pos > 32u * ND_MASK_WORDS) atomicAdd(&stats[0], 1u);  // rare by construction: one counter is enough
+#ifdef ND_FULL_STORE
+        // experiment: the whole 32-byte record rewritten (two 16-byte stores: full sectors) instead of two 4-byte patches
+        srt.pred(i) = make_float4(o.x, o.y, o.z, density + 0.00001f);
+        srt.vel(i) = make_float4(own_vel.x, own_vel.y, own_vel.z, near_density + 0.00001f);
+#else
         density_store(density, near_density, i, srt);
+#endif
     }
 }
 
@@ -1906,6 +1915,25 @@ void wsk_slab_unpack_by_id(hipStream_t s, const uint32_t *all, const uint32_t *c
     if (!max_n) return;
     hipLaunchKernelGGL(k_slab_unpack_by_id, dim3(cdiv(max_n, WS_BLOCK), world), dim3(WS_BLOCK), 0, s, all, cnt, max_n,
                        stride_words, pw, n_global, out);
+}
+
+// x-layer histogram of ALL particles (gathered {id, pos, vel, pred} records of every rank): the input of a re-cut
+// (ws_slab_rebalance).  Every rank computes the same histogram from the same gathered data, hence the same cuts.
+__global__ void __launch_bounds__(WS_BLOCK) k_slab_layer_hist(WsDev d, const uint32_t *__restrict__ all, const uint32_t *__restrict__ cnt,
+                                                              uint32_t max_n, size_t stride_words, uint32_t *__restrict__ hist)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x, r = blockIdx.y;
+    if (t >= min(cnt[4 * r], max_n)) return;
+    const float *f = reinterpret_cast<const float *>(all + (size_t)r * stride_words + (size_t)t * 10u + 1u);
+    atomicAdd(&hist[grid_layer_x(d, f[6])], 1u);  // by PREDICTED x, what the step bins by
+}
+
+void wsk_slab_layer_hist(hipStream_t s, const WsDev &d, const uint32_t *all, const uint32_t *cnt, uint32_t world, uint32_t max_n,
+                         size_t stride_words, uint32_t *hist)
+{
+    if (!max_n) return;
+    hipLaunchKernelGGL(k_slab_layer_hist, dim3(cdiv(max_n, WS_BLOCK), world), dim3(WS_BLOCK), 0, s, d, all, cnt, max_n, stride_words,
+                       hist);
 }
 
 // Loads.  One lane per record of a chunk of a GLOBAL array; the lanes whose particle this slab owns append it to the

@@ -10,7 +10,7 @@ OUT = os.path.join(HERE, "frame_loop")
 
 def build_host():
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", HERE,
-           os.path.join(HERE, "frame_loop.cpp"), "-o", OUT, "-L", PKG, "-lwsfluid", "-Wl,-rpath," + PKG]
+           os.path.join(HERE, "frame_loop.cpp"), "-o", OUT, "-L", PKG, "-lwsfluid", "-pthread", "-Wl,-rpath," + PKG]
     subprocess.check_call(cmd)
     return OUT
 

@@ -96,6 +96,38 @@ class FluidWorker {
         return w;
     }
 
+    // The same worker as ONE x-slab of the domain (multi-GPU: one per GPU; the reference is single-GPU).
+    // Every rank is handed ALL points -- FluidParticlesInitial, :82-85 -- and keeps what ws_slab_assign gives it.
+    // n_ stays the GLOBAL particle count: read_positions / read_vec / reset / write_slice work on global, id-ordered
+    // arrays on a slab handle too (collective calls: every rank makes them at the same point of its frame).
+    static FluidWorker build_slab(const FluidStaticProps &props, const Gravity &gravity, const FluidContainer &container,
+                                  const std::vector<Vec3> &points, unsigned rank, unsigned world, const ws_transport &transport,
+                                  int device = 0, unsigned flags = 0)
+    {
+        FluidWorker w;
+        w.n_ = (uint32_t)points.size();
+        const ws_params p = make_params(props, gravity, container);
+        std::vector<uint32_t> owner(points.size());
+        ws_status st = ws_slab_assign(&p, reinterpret_cast<const float *>(points.data()), w.n_, world, owner.data());
+        if (st != WS_OK) throw WsError(st, ws_last_error(nullptr));
+        std::vector<Vec3> mine;
+        std::vector<uint32_t> ids;
+        for (uint32_t i = 0; i < w.n_; i++)
+            if (owner[i] == rank) {
+                mine.push_back(points[i]);
+                ids.push_back(i);
+            }
+        ws_device_cfg cfg{};
+        cfg.device = device;
+        cfg.rank = rank;
+        cfg.world_size = world;
+        cfg.flags = flags;
+        st = ws_slab_create(&p, reinterpret_cast<const float *>(mine.data()), ids.data(), (uint32_t)mine.size(), w.n_, &cfg,
+                            &transport, &w.h_);
+        if (st != WS_OK) throw WsError(st, ws_last_error(nullptr));
+        return w;
+    }
+
     FluidWorker(FluidWorker &&o) noexcept : h_(o.h_), n_(o.n_) { o.h_ = nullptr; }
     FluidWorker &operator=(FluidWorker &&o) noexcept
     {
@@ -112,6 +144,7 @@ class FluidWorker {
 
     // AppComputeWorker::run / ready, :396,:474
     void run() { check(ws_step(h_)); }
+    void sync() { check(ws_sync(h_)); }
     bool ready()
     {
         int r = 0;

@@ -380,6 +380,11 @@ class SlabWorker:
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
         return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4])}
 
+    def rebalance(self):
+        """ws_slab_rebalance (collective): re-cut the slabs to equal particle counts."""
+        self._L.ws_slab_rebalance.argtypes = [C.c_void_p]
+        self._check(self._L.ws_slab_rebalance(self._h))
+
     def counters(self):
         """Migration counters since creation (ws_slab_counters): owned now, left, arrived, left by the far route."""
         out = (C.c_uint64 * 4)()
