@@ -183,9 +183,9 @@ def test_rebalance_moves_the_cuts_where_static_cuts_overrun(ws):
     def program(s, rank):
         owned = []
         for k in range(steps // 8):
-            s.run(8)
-            s.rebalance()
+            s.rebalance()          # (the record view reports densities / accelerations of the last STEP: re-cut first)
             owned.append(s.num_owned())
+            s.run(8)
         return s.read_vec("particles"), owned
 
     results = ws.slab.run_loopback_program(pos, params, world, program, capacity=cap)
