@@ -181,9 +181,7 @@ def secondary_roofline(counters, label, avg_s):
            "source": "profiles/%s/pmc_windows.json (rocprofv3 --pmc passes of this window) / this run's launch time" % PROFILES_ROUND}
     if p.get("SQ_THREAD_CYCLES_VALU") and p.get("SQ_ACTIVE_INST_VALU"):
         out["lane_utilisation"] = p["SQ_THREAD_CYCLES_VALU"] / 64.0 / p["SQ_ACTIVE_INST_VALU"]
-    if p.get("TA_BUSY_avr") is not None and p.get("GRBM_GUI_ACTIVE"):
-        out["texture_addresser_busy_frac"] = p["TA_BUSY_avr"] / p["GRBM_GUI_ACTIVE"]
-    elif p.get("ta_busy_frac") is not None:
+    if p.get("ta_busy_frac") is not None:
         out["texture_addresser_busy_frac"] = p["ta_busy_frac"]
     return out
 

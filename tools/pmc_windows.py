@@ -21,11 +21,13 @@ for part in "abcl":
                 per[k][c] = sum(v[-steps:]) / steps  # the timed window only
 for k, c in per.items():
     if c.get("TA_BUSY_avr") is not None and c.get("GRBM_GUI_ACTIVE"):
-        c["ta_busy_frac"] = c["TA_BUSY_avr"] / c["GRBM_GUI_ACTIVE"]
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (kernel duration x 2.4 GHz x 8.07 for every kernel checked),
+        # TA_BUSY_avr as the average over the TA instances: busy fraction = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8)
+        c["ta_busy_frac"] = c["TA_BUSY_avr"] / (c["GRBM_GUI_ACTIVE"] / 8.0)
 allw = json.load(open(out_path)) if os.path.exists(out_path) else {}
 allw["%s-%s-w%d-k%d" % (cfg, dist, warm, steps)] = per
 allw["_units"] = ("mean per launch over the window's launches; SQ_INSTS_* = wave-instructions; SQ_WAVE_CYCLES / SQ_WAIT_* / "
                   "SQ_ACTIVE_INST_* in quad-cycles (MI355X_MICROARCH.md); lane utilisation = SQ_THREAD_CYCLES_VALU / 64 / "
-                  "SQ_ACTIVE_INST_VALU; ta_busy_frac = TA_BUSY_avr / GRBM_GUI_ACTIVE")
+                  "SQ_ACTIVE_INST_VALU; ta_busy_frac = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8): GRBM_GUI_ACTIVE is summed over the 8 XCDs")
 json.dump(allw, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {c: round(v, 1) for c, v in cs.items() if c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "ta_busy_frac")} for k, cs in per.items()}))

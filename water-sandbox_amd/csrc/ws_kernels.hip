@@ -124,7 +124,10 @@ __device__ __forceinline__ uint32_t span_at(const WsSpan &sp, uint32_t v) { retu
 // Those wrapped cells hold no neighbour (they are a whole grid extent away), but their run lengths number the
 // candidates of the accept masks: K4 (before the unpack) and K5 (after it) must count the same.  So early launches
 // cut every run to the owned range [base, base + n): a ghost layer's starts clamp to the same ends whatever they
-// hold.  Wave-uniform, nothing on a single-GPU handle.
+// hold.  The listed kernels have an instantiation of their own for early launches (template parameter CUT), so that
+// every other launch -- all of a single-GPU handle's -- compiles to exactly the code without it (a run-time switch,
+// though wave-uniform, cost the dense force kernel 4 % through register allocation alone); the simple kernels test
+// at run time.
 struct WsCut {
     uint32_t lo, hi;
     bool on;
@@ -138,6 +141,15 @@ __device__ __forceinline__ WsCut ws_cut(const WsDev &d)
         c.on = true;
     }
     return c;
+}
+template <bool CUT>
+__device__ __forceinline__ void cut_run_t(const WsDev &d, uint32_t &b, uint32_t &e)
+{
+    if constexpr (CUT) {
+        const uint32_t lo = d.base, hi = d.base + d.dyn[DY_N];
+        b = min(max(b, lo), hi);
+        e = min(max(e, lo), hi);
+    }
 }
 __device__ __forceinline__ void cut_run(const WsCut &c, uint32_t &b, uint32_t &e)
 {
@@ -787,18 +799,22 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
 // reference's hashed table would alias inside one stencil (tiny N: multiplicity table),
 // and the fallback of the listed K5 for particles whose neighbour list overflowed.
 // ---------------------------------------------------------------------------------
-template <bool ALIAS, bool IEEE>
+// CUTMODE: 0 = runs as they are, 1 = cut to the owned range (the early launches' instantiation of the listed kernels),
+// 2 = decide at run time (the simple kernels: one instantiation serves every range)
+template <bool ALIAS, bool IEEE, int CUTMODE = 2>
 __device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSorted srt,
                                                      const uint8_t *__restrict__ mult, float4 o, int c, float &density,
                                                      float &near_density)
 {
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    const WsCut cut = ws_cut(d);
+    WsCut cut = {0u, 0xFFFFFFFFu, false};
+    if constexpr (CUTMODE == 2) cut = ws_cut(d);
     for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
             uint32_t b = start[cc - 1], e = start[cc + 2];
-            cut_run(cut, b, e);
+            if constexpr (CUTMODE == 2) cut_run(cut, b, e);
+            else cut_run_t<CUTMODE == 1>(d, b, e);
             for (uint32_t j = b; j < e; j++) {
                 const float4 q = srt.pred(j);
                 const float ex = q.x - o.x, ey = q.y - o.y, ez = q.z - o.z;
@@ -810,18 +826,20 @@ __device__ __forceinline__ void density_sweep_simple(const WsDev &d, const uint3
     }
 }
 
-template <bool ALIAS, bool IEEE>
+template <bool ALIAS, bool IEEE, int CUTMODE = 2>
 __device__ __forceinline__ void force_sweep_simple(const WsDev &d, const uint32_t *__restrict__ start, WsSorted srt,
                                                    const uint8_t *__restrict__ mult, uint32_t i, float4 o, float4 vel, int c,
                                                    float pressure, float near_pressure, ForceAcc &acc)
 {
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-    const WsCut cut = ws_cut(d);
+    WsCut cut = {0u, 0xFFFFFFFFu, false};
+    if constexpr (CUTMODE == 2) cut = ws_cut(d);
     for (int dx = -1; dx <= 1; dx++) {
         for (int dy = -1; dy <= 1; dy++) {
             const int cc = d.guard + c + dx * rowy + dy * rowz;
             uint32_t b = start[cc - 1], e = start[cc + 2];
-            cut_run(cut, b, e);
+            if constexpr (CUTMODE == 2) cut_run(cut, b, e);
+            else cut_run_t<CUTMODE == 1>(d, b, e);
             for (uint32_t j = b; j < e; j++) {
                 if (j == i) continue;  // `particle_index == neighbour_index`, simulation.wgsl:232
                 const float4 q = srt.pred(j);
@@ -996,7 +1014,7 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
     }
 }
 
-template <bool IEEE>
+template <bool IEEE, bool CUT>
 __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ start,
                                                          const uint32_t *__restrict__ cid_srt, WsSorted srt, WsXYZ sxyz,
                                                          WsMask mask, uint32_t *__restrict__ stats)
@@ -1047,7 +1065,6 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         }
     };
     uint32_t cnt = 0;
-    const WsCut cut = ws_cut(d);
     for (int p = 0; p < 3; p++) {  // dx = -1, 0, +1
         const int cc = d.guard + c + (p - 1) * rowy;
         // unconditional (iv is always a real particle), so the six loads go out together
@@ -1055,9 +1072,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         run_bounds(start, cc - rowz, b0, e0);
         run_bounds(start, cc, b1, e1);
         run_bounds(start, cc + rowz, b2, e2);
-        cut_run(cut, b0, e0);
-        cut_run(cut, b1, e1);
-        cut_run(cut, b2, e2);
+        cut_run_t<CUT>(d, b0, e0);
+        cut_run_t<CUT>(d, b1, e1);
+        cut_run_t<CUT>(d, b2, e2);
         if (!valid) {
             e0 = b0;
             e1 = b1;
@@ -1088,7 +1105,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
 #endif
 
-template <bool IEEE, bool ACCEL_ONLY>
+template <bool IEEE, bool ACCEL_ONLY, bool CUT>
 __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
@@ -1113,7 +1130,6 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     {
         // unconditional loads (iv is always a real particle), six in flight per plane
         const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
-        const WsCut cut = ws_cut(d);
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             uint32_t b[3], e[3];
@@ -1122,7 +1138,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
                 const int cc = d.guard + c + (p - 1) * rowy + (q - 1) * rowz;
                 b[q] = start[cc - 1];  // (one 16-B load for both, as in K4: -4 % sparse, +4.5 % dense here)
                 e[q] = start[cc + 2];
-                cut_run(cut, b[q], e[q]);
+                cut_run_t<CUT>(d, b[q], e[q]);
             }
 #pragma unroll
             for (int q = 0; q < 3; q++) {
@@ -1256,7 +1272,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         }
       }
     } else if (valid) {
-        force_sweep_simple<false, IEEE>(d, start, srt, nullptr, i, o, vel, c, pressure, near_pressure, acc);
+        force_sweep_simple<false, IEEE, CUT ? 1 : 0>(d, start, srt, nullptr, i, o, vel, c, pressure, near_pressure, acc);
     }
     if (valid) force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
@@ -1281,8 +1297,10 @@ static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start,
         WS_LAUNCH((k_density_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
     else if (variant == WS_VARIANT_SIMPLE)
         WS_LAUNCH((k_density_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
+    else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
+        WS_LAUNCH((k_density_listed<IEEE, true>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
     else
-        WS_LAUNCH((k_density_listed<IEEE>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
+        WS_LAUNCH((k_density_listed<IEEE, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
 }
 
 template <bool IEEE, bool ACCEL_ONLY>
@@ -1296,8 +1314,11 @@ static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, c
     else if (variant == WS_VARIANT_SIMPLE)
         WS_LAUNCH((k_force_simple<false, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt,
                   srt, out, accel, cid_out, count, mult);
+    else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, true>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask);
     else
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
                   accel, cid_out, count, mask);
 }
 
