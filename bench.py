@@ -11,6 +11,12 @@ The workload is not stationary: a uniform cloud collapses 
 ~120 steps and the step gets ~3x more expensive, so the line carries TWO windows measured in the same
 run: `value` = steps W..W+K of the trajectory (what the flags ask for), and `settled` = steps
 400..500 (the state the simulation lives in afterwards), each with its own roofline object.
+The whole measurement is repeated --reps times (default 5) on fresh trajectories and the line reports the
+repetition with the MEDIAN time, each window on its own (SURVEY 8(d) protocol); `repetitions` lists them all.
+`roofline.frac` prices the dominant kernel against the HBM roofline by ALGORITHMIC bytes (the contract);
+what actually limits it is in `roofline.limiter` / `roofline.secondary` (VALU issue rate, texture
+addresser, from the committed counter passes of the same window) and `step_traffic` is the counter-measured
+HBM traffic of all five kernels of a step over the step time.
 `value_ieee` is the first window again with WS_FLAG_IEEE_DIVISION (correctly rounded sqrt / division,
 the CPU restatement's arithmetic) instead of the hardware's 1-ULP forms.  `with_readback` is the host
 application's frame pattern over the first window (positions read back every step, overlapped; PCIe

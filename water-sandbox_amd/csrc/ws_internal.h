@@ -274,6 +274,9 @@ struct WsSlab {
     uint64_t migrated_out = 0;
 };
 
+// ws_rccl.cpp (not part of the public header): no-op for a transport that is not the library's own
+extern "C" void ws_rccl_transport_bind_stream(const ws_transport *t, void *stream);
+
 // ---- kernel launchers (ws_kernels.hip) -------------------------------------------
 void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32_t n);
 void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);

@@ -921,7 +921,9 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 #define ND_K 16            // list fill level that triggers a flush
 #endif
 #define ND_ROWS (ND_K + 3) // a trip of 4 candidates may start at fill level K-1
+#ifndef ND_MASK_WORDS
 #define ND_MASK_WORDS 64   // 2048 candidates per particle (256 B of mask rows each; only the words in use are touched)
+#endif
 
 // Workgroup -> tile map of the two neighbour kernels.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
 // share one), each with its own L2: tile = f(b) gives every XCD one CONTIGUOUS eighth of the sorted order (an

@@ -166,11 +166,10 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
     const char *single = getenv("WS_RCCL_SINGLE_COMM");
     if (g_api.CommSplit && !(single && atoi(single) != 0)) {
         // collective over the first communicator; same colour everywhere, ranks keep their order
+        // (not fatal: without a second communicator both streams share the first one, as before round 3)
         if (check(t, g_api.CommSplit(t->comm[0], 0, t->rank, &t->comm[1], nullptr), "ncclCommSplit")) {
             g_api.error = t->error;
-            g_api.CommDestroy(t->comm[0]);
-            delete t;
-            return WS_ERR_COMM;
+            t->comm[1] = nullptr;
         }
     }
     out->ctx = t;
@@ -191,6 +190,16 @@ void ws_rccl_transport_destroy(ws_transport *t)
 }
 
 const char *ws_rccl_last_error(void) { return g_api.error.c_str(); }
+
+// The handle created with this transport names its own (compute) stream: that one keeps to communicator 0, its
+// communication stream to communicator 1 -- whatever streams an earlier handle on the same transport used.
+void ws_rccl_transport_bind_stream(const ws_transport *t, void *stream)
+{
+    if (!t || !t->ctx || t->sendrecv != rccl_sendrecv) return;
+    RcclTransport *r = static_cast<RcclTransport *>(t->ctx);
+    r->first_stream = static_cast<hipStream_t>(stream);
+    r->have_first = true;
+}
 
 // how many communicators the transport drives (2 = one per stream of the slab step); diagnostics / tests
 uint32_t ws_rccl_transport_communicators(const ws_transport *t)
