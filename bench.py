@@ -57,8 +57,10 @@ PROFILES = os.path.join(ROOT, "profiles", PROFILES_ROUND)
 # VALU issue peak of the chip: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (a packed-f32 or
 # transcendental instruction takes more: the fraction below is a lower bound of how busy the VALU issue ports are)
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
+# the step loop's instantiations as rocprofv3 names them: K4 <IEEE = false, CUT = false>, K5 <IEEE = false, ACCEL_ONLY =
+# false, CUT = false> (CUT: the early launches of a slab step)
 STEP_KERNELS = {"cell_scan": "k_scan<true>", "cell_scatter": "k_place", "reorder": "k_reorder<true>",
-                "density": "k_density_listed<false>", "force_integrate_bin": "k_force_listed<false, false>"}
+                "density": "k_density_listed<false, false>", "force_integrate_bin": "k_force_listed<false, false, false>"}
 
 KERNEL_LABEL = {
     "density": "density (K4 update_density: radius sweep + accept masks)",

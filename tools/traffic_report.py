@@ -26,8 +26,8 @@ cal = {"kernel": "k_reorder<true>", "reorder_fetch_raw": fetch.get("k_reorder<tr
 out = {"window": {"config": cfg, "dist": dist, "warmup": warm, "steps": steps, "particles": n},
        "units": "bytes per launch, mean over the timed window",
        "fetch_raw": fetch, "write_raw": write, "calibration": cal}
-force = [k for k in fetch if k.startswith("k_force") and not k.endswith(", true>")][0]  # not the on-demand accel pass
-dens = [k for k in fetch if k.startswith("k_density")][0]
+force = "k_force_listed<false, false, false>"  # <IEEE, ACCEL_ONLY, CUT>: the step's launch, not the on-demand accel pass
+dens = "k_density_listed<false, false>"
 out["bytes_per_launch"] = {"force_integrate_bin": 2.0 * fetch[force] + write[force],
                            "density": 2.0 * fetch[dens] + write[dens]}
 out["bytes_per_launch_note"] = "2 x FETCH_SIZE (gfx950 half-count correction for 16-B/lane reads) + WRITE_SIZE"
