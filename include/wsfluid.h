@@ -287,6 +287,9 @@ ws_status ws_slab_read_particles(ws_handle *h, ws_particle80 *out, uint32_t *out
  * particles are redistributed like on a re-grid and the run continues bit-identically to a single handle.  Cheap
  * when nothing needs to move (one gather; every rank decides alike). */
 ws_status ws_slab_rebalance(ws_handle *h);
+/* Host-only: the cuts ws_slab_rebalance chooses for an x-layer histogram (hist[nx] particles per cell layer; cuts_out holds
+ * world_size + 1 entries, cuts_out[0] = 0, cuts_out[world_size] = nx, strictly increasing). */
+ws_status ws_slab_balanced_cuts(const uint32_t *hist, uint32_t nx, uint32_t world_size, uint32_t *cuts_out);
 /* Migration counters of this slab since it was created, as of the last migration that has run (waits for enqueued
  * steps): out[0] = particles owned now, out[1] = particles that left, out[2] = particles that arrived, out[3] = of
  * those that left, the ones that crossed more than one slab in a step (the all-gathered route).  The reference is a

@@ -79,6 +79,28 @@ class Protocol:
         self.tables[step] = np.stack([o.numpy()[0, :HDR] for o in out])
         return [o.numpy()[1:1 + int(o.numpy()[0, 0]), :width] for o in out]
 
+    def gather_by_id(self, ids, payload, n_global):
+        """The host's global reads on slab handles (csrc/ws_slab.inc slab_gather): ONE all-gather of the owned counts, ONE
+        of {id, payload} records sized by the largest count, then a scatter by id -- every rank ends with the whole,
+        id-ordered array.  Returns (array[n_global, width], counts)."""
+        mine = torch.tensor([len(ids)], dtype=torch.int64)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(counts, mine)
+        counts = [int(c.item()) for c in counts]
+        assert sum(counts) == n_global, "particle count not conserved across slabs: %r" % (counts,)
+        cap, width = max(counts), payload.shape[1]
+        rec = torch.zeros((cap, 1 + width), dtype=torch.float64)
+        rec[: len(ids), 0] = torch.from_numpy(ids.astype(np.float64))
+        rec[: len(ids), 1:] = torch.from_numpy(payload.astype(np.float64))
+        allr = [torch.zeros_like(rec) for _ in range(self.world)]
+        dist.all_gather(allr, rec)
+        out = np.full((n_global, width), np.nan)
+        for r, a in enumerate(allr):
+            a = a.numpy()[: counts[r]]
+            out[a[:, 0].astype(np.int64)] = a[:, 1:]
+        assert not np.isnan(out).any()
+        return out, counts
+
     def check(self, step):
         """What ws_step does first: the table of step - LAG; any rank's error bit fails every rank at this step."""
         t = self.tables.get(step - self.LAG)
@@ -90,6 +112,7 @@ class Protocol:
 def main():
     out_path, steps = sys.argv[1], int(sys.argv[2])
     halo_cap = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    recut_at = int(sys.argv[4]) if len(sys.argv) > 4 else -1  # step before which the slabs are re-cut (ws_slab_rebalance)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     proto = Protocol(rank, world, halo_cap=halo_cap, mig_cap=512, far_cap=64)
@@ -113,12 +136,36 @@ def main():
     lo, hi = cuts[rank], cuts[rank + 1]
     max_err = 0.0
     failed_at = -1
+    frames = []
     for step in range(steps):
         try:
             proto.check(step)
         except OverflowError:
             failed_at = step  # every rank raises here, at the same step, outside any collective
             break
+        # update(): every rank reads the id-ordered positions of ALL particles (src/fluid_compute.rs:478-485)
+        allpos, counts = proto.gather_by_id(ids, state["position"][:, :3], n)
+        frames.append(allpos.astype(np.float32))
+        if step == recut_at:
+            # ws_slab_rebalance: gather the full state, the x-layer histogram of all predicted positions (identical on
+            # every rank), cuts of equal particle counts from the library's host function, every rank keeps its share
+            full, _ = proto.gather_by_id(ids, np.c_[state["position"][:, :3], state["velocity"][:, :3],
+                                                    state["predicted_position"][:, :3]], n)
+            gxa = np.clip(np.floor(full[:, 6].astype(np.float32) / H).astype(np.int64) - org, 0, nx - 1)
+            hist = np.bincount(gxa, minlength=nx).astype(np.uint32)
+            newcuts = np.zeros(world + 1, np.uint32)
+            lib = ws.load_library()
+            import ctypes as C
+            lib.ws_slab_balanced_cuts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+            assert lib.ws_slab_balanced_cuts(hist.ctypes.data, nx, world, newcuts.ctypes.data) == 0
+            cuts = [int(c) for c in newcuts]
+            lo, hi = cuts[rank], cuts[rank + 1]
+            sel = np.flatnonzero((gxa >= lo) & (gxa < hi))
+            ids = sel.astype(np.int64)
+            state = np.zeros(len(sel), O.PARTICLE_DTYPE)
+            state["position"][:, :3] = full[sel, 0:3]; state["velocity"][:, :3] = full[sel, 3:6]
+            state["predicted_position"][:, :3] = full[sel, 6:9]
+            owned_after_recut = len(sel)
         gx = np.clip(xcell(params, state["predicted_position"], org), 0, nx - 1)
         assert np.all((gx >= lo) & (gx < hi)) or proto.err, "ownership invariant"
         # halo A: predicted positions (+ velocity, ids) of my first / last owned layer
@@ -127,11 +174,19 @@ def main():
         ghosts = proto.exchange(pack(gx == lo), pack(gx == hi - 1), proto.halo_cap, len(state), step, ERR_HALO)
         g = [a for a in (ghosts["left"], ghosts["right"]) if a is not None and len(a)]
         g = np.concatenate(g) if g else np.zeros((0, 7))
-        local = np.zeros(len(state) + len(g), O.PARTICLE_DTYPE)
+        # (padded to a power of two with far-away dummies: the oracle hashes into as many buckets as it has particles, and
+        # for an arbitrary count two cells of one 27-stencil can share a bucket -- the reference's table then counts a
+        # neighbour twice; the slab sizes of this model are arbitrary, the GPU path uses the global N)
+        real = len(state) + len(g)
+        padded = 1 << max(12, int(real - 1).bit_length())
+        local = np.zeros(padded, O.PARTICLE_DTYPE)
+        local["predicted_position"][real:, 0] = 1.0e4 + 10.0 * np.arange(padded - real, dtype=np.float32)
+        local["predicted_position"][real:, 1:3] = 1.0e4
+        local["position"][real:] = local["predicted_position"][real:]
         local[: len(state)] = state
-        local["predicted_position"][len(state):, :3] = g[:, 1:4].astype(np.float32)
-        local["velocity"][len(state):, :3] = g[:, 4:7].astype(np.float32)
-        local["position"][len(state):] = local["predicted_position"][len(state):]
+        local["predicted_position"][len(state):real, :3] = g[:, 1:4].astype(np.float32)
+        local["velocity"][len(state):real, :3] = g[:, 4:7].astype(np.float32)
+        local["position"][len(state):real] = local["predicted_position"][len(state):real]
         gid = g[:, 0].astype(np.int64)
         orc = oracle_from_params(O, local["position"][:, :3].copy(), params)
         orc.set_particles(local)
@@ -144,9 +199,9 @@ def main():
         if d:
             d = np.concatenate(d)
             assert np.array_equal(d[:, 0].astype(np.int64), gid) or proto.err  # same order as halo A
-            wrong = np.abs(orc.particles["density"][len(state):, 0] - d[:, 1]).max() if len(d) else 0.0
-            orc.particles["density"][len(state):] = d[:, 1:3].astype(np.float32)
-            orc.particles["pressure"][len(state):] = d[:, 3:5].astype(np.float32)
+            wrong = np.abs(orc.particles["density"][len(state):real, 0] - d[:, 1]).max() if len(d) else 0.0
+            orc.particles["density"][len(state):real] = d[:, 1:3].astype(np.float32)
+            orc.particles["pressure"][len(state):real] = d[:, 3:5].astype(np.float32)
             if step == 0 and len(d):
                 # without halo B the ghosts' locally computed densities are wrong (missing neighbours)
                 assert wrong > 1.0
@@ -173,7 +228,8 @@ def main():
                 add["predicted_position"][:, :3] = a[:, 7:10]; add["density"] = a[:, 10:12]
                 add["acceleration"][:, :3] = a[:, 12:15]
                 state = np.concatenate([state, add]); ids = np.concatenate([ids, a[:, 0].astype(np.int64)])
-    np.savez(out_path % rank, ids=ids, state=state, failed_at=failed_at)
+    np.savez(out_path % rank, ids=ids, state=state, failed_at=failed_at, frames=np.array(frames),
+             cuts=np.array(cuts), owned_after_recut=locals().get("owned_after_recut", -1))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -168,3 +168,25 @@ def test_no_smoothing_radius_runs_out_of_cell_tables(ws):
             assert lib.ws_slab_assign(C.byref(p), pos.ctypes.data, 4, 2, out.ctypes.data) == 0, (name, h)
     p = ws.make_params(container_size=ws.workloads.CONFIGS["c5"][1], smoothing_radius=1e-6)
     assert lib.ws_slab_assign(C.byref(p), pos.ctypes.data, 4, 2, out.ctypes.data) == 1  # WS_ERR_INVALID_ARG
+
+
+def test_balanced_cuts_are_monotone_complete_and_balanced(ws):
+    """Host-only: the re-cut rule of ws_slab_rebalance.  For any histogram the cuts start at 0, end at nx, increase
+    strictly (every slab keeps a layer), and no slab exceeds its fair share by more than the layer that crosses it."""
+    lib = ws.load_library()
+    lib.ws_slab_balanced_cuts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(7)
+    for nx, world in ((68, 3), (68, 8), (260, 8), (9, 8), (5, 5), (1028, 8)):
+        for shape in ("flat", "piled", "spike", "empty-left"):
+            hist = {"flat": np.full(nx, 1000), "piled": (np.arange(nx) ** 3) % 100000 + 1,
+                    "spike": np.where(np.arange(nx) == nx // 2, 10 ** 6, 3),
+                    "empty-left": np.where(np.arange(nx) < nx // 2, 0, rng.integers(1, 5000, nx))}[shape].astype(np.uint32)
+            cuts = np.zeros(world + 1, np.uint32)
+            assert lib.ws_slab_balanced_cuts(hist.ctypes.data, nx, world, cuts.ctypes.data) == 0
+            assert cuts[0] == 0 and cuts[-1] == nx and np.all(np.diff(cuts.astype(np.int64)) >= 1), (nx, world, shape, cuts)
+            total, share = int(hist.sum()), int(hist.sum()) / world
+            for r in range(world):
+                owned = int(hist[cuts[r]:cuts[r + 1]].sum())
+                if cuts[r + 1] - cuts[r] > 1:   # a slab of several layers never overshoots by more than its last layer
+                    assert owned <= share + int(hist[cuts[r]:cuts[r + 1]].max()) + 1, (nx, world, shape, r, owned, share)
+    assert lib.ws_slab_balanced_cuts(hist.ctypes.data, 4, 5, cuts.ctypes.data) == 1   # more slabs than layers

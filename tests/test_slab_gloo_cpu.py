@@ -53,3 +53,38 @@ def test_two_rank_slab_model_capacity_overrun_fails_on_every_rank_alike(tmp_path
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     failed = [int(np.load(pattern % r)["failed_at"]) for r in range(2)]
     assert failed[0] == failed[1] and 2 <= failed[0] <= 3, failed
+
+
+def test_two_rank_global_reads_and_a_recut(oracle, ws, tmp_path):
+    """The host's per-frame boundary on slabs, on CPU with two gloo ranks: every frame both ranks read the id-ordered
+    positions of ALL particles (counts all-gather + records all-gather + scatter by id: csrc/ws_slab.inc slab_gather) and
+    must see the same array; before step 3 the slabs are re-cut to equal particle counts with the library's own cut rule
+    (ws_slab_balanced_cuts) from the gathered state.  The run still matches the single-domain oracle and conserves
+    particles."""
+    from util import oracle_from_params
+
+    steps = 6
+    pattern = str(tmp_path / "rank_%d.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", OMP_NUM_THREADS="2", WSO_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29545", os.path.join(ROOT, "tests", "dist_cpu_slab_model.py"), pattern, str(steps), "1024", "3"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    d = [np.load(pattern % r) for r in range(2)]
+    assert np.array_equal(d[0]["frames"], d[1]["frames"]) and d[0]["frames"].shape[0] == steps   # every rank, every frame
+    assert np.array_equal(d[0]["cuts"], d[1]["cuts"])                                             # every rank decides alike
+    params = ws.make_params(container_size=(8.0, 5.0, 5.0), gravity=(5.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(4096, 11, list(params.ext_min), list(params.ext_max))
+    nx = int(d[0]["cuts"][-1])
+    assert list(d[0]["cuts"]) != [0, nx // 2, nx], "the tilted gravity should have moved the cut"
+    owned = [int(x["owned_after_recut"]) for x in d]
+    assert sum(owned) == 4096 and abs(owned[0] - owned[1]) < 4096 // 4, owned
+    orc = oracle_from_params(oracle, pos, params)
+    for k in range(steps):
+        err = np.max(np.abs(d[0]["frames"][k].astype(np.float64) - orc.particles["position"][:, :3].astype(np.float64)))
+        assert err <= 2e-5 * 8.0, (k, err)
+        orc.step(oracle.SORT_FAST)
+    seen = np.zeros(len(pos), np.int32)
+    for x in d:
+        np.add.at(seen, x["ids"], 1)
+    assert np.all(seen == 1)

@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "ws_rccl_transport_destroy", "ws_rccl_last_error", "ws_rccl_transport_communicators",
     "ws_local_hub_create", "ws_local_hub_destroy", "ws_local_transport_create", "ws_local_transport_destroy", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
     "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
-    "ws_grid_dims", "ws_read_stats", "ws_slab_assign", "ws_slab_create", "ws_slab_read_particles", "ws_slab_rebalance",
+    "ws_grid_dims", "ws_read_stats", "ws_slab_assign", "ws_slab_create", "ws_slab_read_particles", "ws_slab_rebalance", "ws_slab_balanced_cuts",
 ]
 
 
