@@ -203,6 +203,18 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz);
  * teacher forcing use this. */
 ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
 
+/* ---- the per-frame calls above on a SLAB handle (multi-GPU, below) ---------------------------------------------
+ * ws_read_positions / _begin / _end, ws_read_speeds, ws_read_particles, ws_read_sort_view, ws_reset, ws_write_particles
+ * and a ws_set_params that changes the smoothing radius or the container work on slab handles too, over GLOBAL,
+ * id-ordered arrays (n_global entries), as COLLECTIVE calls: every rank makes the same call at the same point of its
+ * frame, as the ranks of a multi-GPU host do anyway.
+ *   reads:   every rank receives the whole array (the owned records of all slabs are all-gathered and scattered by id
+ *            on the device); a rank that does not need it passes NULL and only contributes.
+ *   loads:   every rank passes the SAME global array (what FluidParticlesInitial holds, src/fluid_compute.rs:82-85) and
+ *            keeps the particles its cuts own; no data moves between ranks.  Sticky errors are cleared.
+ *   re-grid: the particles are redistributed by the new cuts (any particle may change owner).
+ * ws_num_particles stays the number of particles THIS slab owns. */
+
 /* ---- multi-GPU: one handle = one x-slab of the domain, one process per GPU ------------------
  *
  * The domain is cut into world_size slabs along x on cell boundaries (x is the slowest axis of the

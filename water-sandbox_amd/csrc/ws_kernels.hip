@@ -975,8 +975,12 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
     bool more = rem > 0;
     auto trip = [&]() {
         const nd_f4 X = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.x) + off);
+#ifdef ND_ABLATE_PLANES  // ablation (wrong results): one candidate load per trip instead of three -- is phase 1 bound by its loads?
+        const nd_f4 Y = X, Z = X;
+#else
         const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.y) + off);
         const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.z) + off);
+#endif
         __builtin_amdgcn_sched_barrier(0);  // the three loads are issued before any is consumed
 #ifdef WS_EXP_COUNT
         { const unsigned long long act = __ballot(true); if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) { atomicAdd(&g_exp[1], 1u); atomicAdd(&g_exp[3], (uint32_t)__popcll(act)); } }
