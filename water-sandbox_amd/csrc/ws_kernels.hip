@@ -1081,6 +1081,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         cut_run_t<CUT>(d, b0, e0);
         cut_run_t<CUT>(d, b1, e1);
         cut_run_t<CUT>(d, b2, e2);
+#ifdef ND_ABLATE_EMPTY  // ablation (wrong results): every run empty -- what is K4 without its candidates?
+        e0 = b0; e1 = b1; e2 = b2;
+#endif
         if (!valid) {
             e0 = b0;
             e1 = b1;
