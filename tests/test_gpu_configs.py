@@ -130,3 +130,24 @@ def test_c4_in_four_slabs_matches_the_single_handle(ws, monkeypatch, overlap):
     assert sum(owned) == pos.shape[0]
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_c5_in_eight_slabs_matches_the_single_handle(ws):
+    """BASELINE.json config 5 (67 108 864 particles) in its 8-GPU decomposition (eight x-slabs; loopback transport on the
+    one test GPU, ~60 GB of HBM): the host's global read returns, on the first and the last rank, id-ordered positions
+    bit-identical to the single handle's, and the slabs own all particles between them."""
+    pos, params = ws.workloads.make_workload("c5", "cloud")
+    steps = 3
+    w = ws.FluidWorker(pos, params)
+    w.run(steps)
+    want = w.read_positions()
+    w.close()
+
+    def program(s, rank):
+        s.run(steps)
+        got = s.read_positions(want=(rank in (0, 7)))   # the other ranks only contribute to the collective read
+        return None if got is None else bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))), s.num_owned()
+
+    res = ws.slab.run_loopback_program(pos, params, 8, program)
+    assert sum(r[1] for r in res) == pos.shape[0]
+    assert res[0][0] is True and res[7][0] is True
