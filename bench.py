@@ -59,8 +59,19 @@ PROFILES = os.path.join(ROOT, "profiles", PROFILES_ROUND)
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
 # the step loop's instantiations as rocprofv3 names them: K4 <IEEE = false, CUT = false>, K5 <IEEE = false, ACCEL_ONLY =
 # false, CUT = false> (CUT: the early launches of a slab step)
-STEP_KERNELS = {"cell_scan": "k_scan<true>", "cell_scatter": "k_place", "reorder": "k_reorder<true>",
+# (k_scan<ZERO = true, cells per thread>: 64 from 2^21 cells on, 32 below)
+STEP_KERNELS = {"cell_scan": "k_scan<true", "cell_scatter": "k_place", "reorder": "k_reorder<true>",
                 "density": "k_density_listed<false, false>", "force_integrate_bin": "k_force_listed<false, false, false>"}
+
+
+def _by_kernel(table, name):
+    """The entry of a per-kernel counter table whose rocprofv3 kernel name is `name` (or starts with it)."""
+    if not table:
+        return None
+    if name in table:
+        return table[name]
+    hits = [v for k, v in table.items() if k.startswith(name)]
+    return hits[0] if len(hits) == 1 else None
 
 KERNEL_LABEL = {
     "density": "density (K4 update_density: radius sweep + accept masks)",
@@ -163,7 +174,7 @@ def step_traffic(counters, ms_per_step):
         return None
     per = {}
     for label, kname in STEP_KERNELS.items():
-        f, w = t["fetch_raw"].get(kname), t["write_raw"].get(kname)
+        f, w = _by_kernel(t["fetch_raw"], kname), _by_kernel(t["write_raw"], kname)
         if f is None or w is None:
             return None
         per[label] = 2.0 * f + w
@@ -177,7 +188,7 @@ def step_traffic(counters, ms_per_step):
 def secondary_roofline(counters, label, avg_s):
     """What the counters say bounds the kernel: VALU issue (wave-instructions per second against the chip's issue peak)
     with the scalar instruction stream, the lane utilisation and the texture-addresser busy fraction next to it."""
-    p = (counters.get("pmc_windows.json") or {}).get(STEP_KERNELS[label])
+    p = _by_kernel(counters.get("pmc_windows.json"), STEP_KERNELS[label])
     if not p or avg_s <= 0:
         return None
     valu = p.get("SQ_INSTS_VALU")

@@ -25,10 +25,14 @@
 #pragma clang fp contract(off)
 
 #define WS_BLOCK 256
-#ifndef WS_SCAN_ITEMS
-#define WS_SCAN_ITEMS 32  // per thread: the look-back chain is ~1 us per 64 tiles, so few large tiles (C3: 8/16/32 -> 54/39/32 us)
-#endif
-#define WS_SCAN_TILE (WS_BLOCK * WS_SCAN_ITEMS)
+// Cells per thread of the scan.  The look-back chain is ~1 us per 64 tiles, so few large tiles (C3, 5.7 M cells:
+// 8 / 16 / 32 / 64 / 96 / 128 items -> 54 / 39 / 27 / 23 / 22.5 / 25 us); but a small grid wants more, smaller tiles to
+// fill the chip (C2 and the reference's default 65 536 particles: 64 items cost +2.7 us of a 54-75 us step).  Two
+// instantiations, chosen by the grid size.
+#define WS_SCAN_ITEMS_SMALL 32
+#define WS_SCAN_ITEMS_LARGE 64
+#define WS_SCAN_LARGE_FROM (1u << 21)  // cells
+#define WS_SCAN_TILE_MIN (WS_BLOCK * WS_SCAN_ITEMS_SMALL)
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
@@ -272,7 +276,7 @@ __device__ __forceinline__ uint32_t wave_run_atomic_inc(uint32_t *__restrict__ t
 // another epoch reads as "not yet written", so nothing is cleared between launches.  A descriptor carries its
 // whole message in one 64-bit word, so relaxed device-scope atomics suffice (acquire / release at agent scope
 // would write back and invalidate the XCD's L2 around every access: measured 8x slower).
-template <bool ZERO>
+template <bool ZERO, int WS_SCAN_ITEMS>
 __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count, uint32_t nitems,
                                                    uint32_t *__restrict__ state, uint32_t *__restrict__ start,
                                                    uint32_t *__restrict__ cursor, uint32_t start_offset, uint32_t ntiles)
@@ -288,6 +292,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count,
     // A tile is WS_SCAN_ITEMS / 4 chunks of WS_BLOCK uint4: thread t owns uint4 number t of every chunk, so
     // every load and store of the tile is a coalesced 16 B per lane.
     constexpr int Q = WS_SCAN_ITEMS / 4;
+    constexpr uint32_t WS_SCAN_TILE = WS_BLOCK * WS_SCAN_ITEMS;
     const uint32_t tbase = tile * WS_SCAN_TILE;
     uint4 v[Q];
     uint32_t excl[Q], total = 0;
@@ -390,20 +395,27 @@ __global__ void __launch_bounds__(WS_BLOCK) k_scan(uint32_t *__restrict__ count,
 }
 
 // words of scan state for `nitems` items (zero-initialised once by the owner)
-uint32_t wsk_scan_state_words(uint32_t nitems) { return 2u + 2u * cdiv(nitems, WS_SCAN_TILE); }
+uint32_t wsk_scan_state_words(uint32_t nitems) { return 2u + 2u * cdiv(nitems, WS_SCAN_TILE_MIN); }  // (the smaller tile: more descriptors)
 
 // start_body points at the first real entry (after the guard); entry [nitems] and the
 // guards are constant and written once by the host.
 void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t nitems,
               bool zero_count, uint32_t base)
 {
-    const uint32_t ntiles = cdiv(nitems, WS_SCAN_TILE);
-    if (zero_count)
-        hipLaunchKernelGGL(k_scan<true>, dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor,
-                           base, ntiles);
-    else
-        hipLaunchKernelGGL(k_scan<false>, dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor,
-                           base, ntiles);
+    // (the tile size is a function of the buffer's length, so every launch on a state buffer draws the same number of
+    // tickets -- what the epoch arithmetic of the kernel relies on)
+    const bool large = nitems >= WS_SCAN_LARGE_FROM;
+    const uint32_t ntiles = cdiv(nitems, WS_BLOCK * (large ? WS_SCAN_ITEMS_LARGE : WS_SCAN_ITEMS_SMALL));
+#define WS_SCAN_LAUNCH(Z, I) \
+    hipLaunchKernelGGL((k_scan<Z, I>), dim3(ntiles), dim3(WS_BLOCK), 0, s, count, nitems, state, start_body, cursor, base, ntiles)
+    if (zero_count) {
+        if (large) WS_SCAN_LAUNCH(true, WS_SCAN_ITEMS_LARGE);
+        else WS_SCAN_LAUNCH(true, WS_SCAN_ITEMS_SMALL);
+    } else {
+        if (large) WS_SCAN_LAUNCH(false, WS_SCAN_ITEMS_LARGE);
+        else WS_SCAN_LAUNCH(false, WS_SCAN_ITEMS_SMALL);
+    }
+#undef WS_SCAN_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------
