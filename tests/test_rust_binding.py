@@ -128,3 +128,57 @@ def test_status_constants_of_the_shim_match_the_header():
 
 def test_header_parser_sees_every_declared_function(ws):
     assert sorted(c_prototypes()) == sorted(ws.fluid.ABI_SYMBOLS)
+
+
+def _call_sites(text, name):
+    """Argument counts of every call `name(...)` in `text` outside the extern block (top-level commas + 1)."""
+    out = []
+    for m in re.finditer(r"\b%s\s*\(" % re.escape(name), text):
+        i, depth, commas, empty = m.end(), 1, 0, True
+        while depth and i < len(text):
+            c = text[i]
+            if c in "([{":
+                depth += 1
+            elif c in ")]}":
+                depth -= 1
+            elif c == "," and depth == 1:
+                commas += 1
+            if depth and not c.isspace():
+                empty = False
+            i += 1
+        out.append(0 if empty else commas + 1)
+    return out
+
+
+def test_every_call_site_in_the_shim_passes_as_many_arguments_as_the_prototype_takes():
+    block = rust_extern_block(RUST)
+    body = RUST[RUST.index('extern "C"'):]
+    body = body[body.index("\n}") + 2:]          # everything after the extern block
+    body = re.sub(r"//[^\n]*", "", body)          # comments mention the functions too
+    called = 0
+    for name, (_, params) in block.items():
+        for argc in _call_sites(body, name):
+            assert argc == len(params), "%s called with %d arguments, declared with %d" % (name, argc, len(params))
+            called += 1
+    assert called >= len(block)                    # every bound function is used
+    for name in re.findall(r"\b(ws_[a-z0-9_]+)\s*\(", body):
+        assert name in block, "the shim calls %s without binding it" % name
+
+
+def test_the_shim_keeps_the_reference_plugin_surface_and_system_sets():
+    """Names and schedule placement the reference defines (src/fluid_compute.rs:369-435,
+    src/schedule.rs:24-36) and the shim must keep so that main.rs / hud.rs need no change."""
+    for needle in ("pub struct FluidPlugin", "pub struct FluidComputePlugin", "pub struct FluidStaticProps",
+                   "pub struct FluidParticlesInitial", "struct FluidParticleLabel(usize)", "fn setup(", "fn update(",
+                   "fn despawn_liquid(",
+                   "add_systems(OnExit(GameState::Menu), setup)",
+                   "add_systems(Update, update.in_set(InGameSet::EntityUpdates))",
+                   "add_systems(Update, despawn_liquid.in_set(InGameSet::DespawnEntities))",
+                   "in_set(ShaderPhysicsSet::Prepare)", "in_set(ShaderPhysicsSet::Pass)",
+                   "init_resource::<FluidStaticProps>()", "init_resource::<FluidParticlesInitial>()"):
+        assert needle in RUST, needle
+    # the defaults of FluidStaticProps (src/fluid_compute.rs:20-27,:67-79)
+    for field, value in (("collision_damping", "0.95"), ("smoothing_radius", "0.25"), ("target_density", "10."),
+                         ("pressure_scalar", "22."), ("near_pressure_scalar", "2."), ("viscosity_strength", "0.1")):
+        assert re.search(r"%s:\s*%s\s*," % (field, re.escape(value)), RUST), field
+    assert RUST.count("{") == RUST.count("}") and RUST.count("(") == RUST.count(")")
