@@ -88,3 +88,44 @@ def test_a_host_transport_is_never_captured(ws):
         assert st["graph_steps"] == 0
         for f in want.dtype.names:
             assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_captured_slab_step_survives_loads_re_grids_and_re_cuts(ws):
+    """One rank through the RCCL transport with WS_FLAG_GRAPH, through everything that invalidates a capture: a reset, a
+    state upload, a smoothing-radius change (arrays re-allocated), a re-cut, a parameter change -- every time the next
+    steady-state step is captured again and the results equal the plain single handle given the same calls."""
+    size = (16.0, 9.0, 9.0)
+    params = ws.make_params(container_size=size, gravity=(6.0, -9.8, 0.0, 0.0))
+    radius = ws.make_params(container_size=size, gravity=(6.0, -9.8, 0.0, 0.0), smoothing_radius=0.35)
+    later = ws.make_params(container_size=size, gravity=(-6.0, -9.8, 1.0, 0.0), smoothing_radius=0.35, viscosity_strength=0.3)
+    pos = ws.workloads.uniform_cloud(50000, 17, list(params.ext_min), list(params.ext_max))
+
+    def program(w, slab):
+        w.run(6)
+        state = w.read_vec("particles")
+        w.reset(pos)
+        w.run(5)
+        (w.write_particles if slab else lambda s: w.write_slice("particles", s))(state)
+        w.run(5)
+        w.set_params(radius)
+        w.run(5)
+        if slab:
+            w.rebalance()
+        w.run(5)
+        w.set_params(later)
+        w.run(5)
+        return w.read_vec("particles"), w.read_positions(), w.stats()
+
+    d = ws.FluidWorker(pos, params)
+    want, want_pos, _ = program(d, False)
+    d.close()
+    tr = ws.slab.NativeRcclTransport(ws.slab.NativeRcclTransport.unique_id(), 0, 1, 0)
+    ids = np.arange(pos.shape[0], dtype=np.uint32)
+    s = ws.slab.SlabWorker(pos, ids, pos.shape[0], params, 0, 1, tr, graph=True)
+    got, got_pos, st = program(s, True)
+    s.close()
+    tr.close()
+    assert st["graph_steps"] >= 20, st
+    assert np.array_equal(got_pos.view(np.uint32), want_pos.view(np.uint32))
+    for f in want.dtype.names:
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
