@@ -34,7 +34,7 @@ typedef enum ws_status {
     WS_ERR_OUT_OF_MEMORY = 3, /* hipMalloc failed or the cell grid would not fit */
     WS_ERR_HIP = 4,           /* any other HIP runtime error (text in ws_last_error) */
     WS_ERR_COMM = 5,          /* RCCL error in the multi-GPU halo exchange */
-    WS_ERR_UNSUPPORTED = 6,   /* e.g. bit-exact reference views for non power-of-two N */
+    WS_ERR_UNSUPPORTED = 6,   /* e.g. WS_FLAG_REFERENCE_ORDER on the product library, ws_create with world_size > 1 */
     WS_ERR_NOT_READY = 7      /* ws_try_* variants only */
 } ws_status;
 

@@ -662,7 +662,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     if (n > WS_MAX_SLOTS - 16u) return fail(nullptr, WS_ERR_INVALID_ARG, "more than 2^27 particles on one device");
     ws_status st = validate_params(nullptr, params);
     if (st) return st;
-    if (cfg && cfg->world_size > 1) return fail(nullptr, WS_ERR_UNSUPPORTED, "multi-GPU slabs are created with ws_create_slab");
+    if (cfg && cfg->world_size > 1) return fail(nullptr, WS_ERR_UNSUPPORTED, "multi-GPU slabs are created with ws_slab_create");
 #ifndef WS_WITH_REFCHECK
     if (cfg && (cfg->flags & WS_FLAG_REFERENCE_ORDER))
         return fail(nullptr, WS_ERR_UNSUPPORTED,
