@@ -89,6 +89,11 @@ def parse_args():
     ap.add_argument("--replicate", action="store_true",
                     help="N GPUs: the config replicated N times along x (e.g. --config c3 --replicate: 4 194 304 "
                          "particles per GPU at every N) instead of BASELINE.json's C4 / C5 geometry")
+    ap.add_argument("--copies", type=int, default=0,
+                    help="the config replicated this many times along x whatever the GPU count (one GPU: the like-for-like "
+                         "run of an N-GPU --replicate workload, e.g. --config c3 --copies 2 = what --gpus 2 runs)")
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="skip the north_star leg (C4, 16.7 M particles, on this one GPU: steps 400..500)")
     ap.add_argument("--reps", type=int, default=5,
                     help="repetitions of the whole measurement (fresh trajectory each: W warm-up steps, K timed steps, the "
                          "run-up to the settled window and its 100 timed steps); the line reports the MEDIAN repetition "
@@ -245,6 +250,8 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed, dominant)
         # bytes).  It is NOT what limits the kernel: the counters say VALU issue and the texture addresser (`limiter`,
         # `secondary`), and its real HBM traffic is `traffic` (about 1 x the algorithmic bytes).
         "bound": "hbm",
+        "priced_against": "hbm (algorithmic bytes / launch time against the 8 TB/s HBM roofline: the contract's pricing, not the limiter)",
+        "bound_by_counters": "valu_issue + texture_addresser",
         "limiter": "valu_issue + texture_addresser (divergent 16-B gathers), not HBM: see `secondary`; DESIGN.md 5",
         "secondary": secondary,
         "achieved": achieved,
@@ -261,6 +268,25 @@ def roofline_of(prof, owned, config, dist, warmup, steps, distributed, dominant)
     }
 
 
+def same_config_one_gpu(cfg_name, dist):
+    """The committed one-GPU line of the configuration an N-GPU run cuts into slabs (profiles/rNN/bench_<cfg>_one_gpu.json,
+    newest round first): {ms_per_step, window, settled_ms_per_step, source}, or None."""
+    if dist != "cloud":
+        return None
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        path = os.path.join(ROOT, "profiles", rnd, "bench_%s_one_gpu.json" % cfg_name)
+        try:
+            with open(path) as f:
+                line = json.load(f)
+        except (OSError, ValueError):
+            continue
+        return {"ms_per_step": line.get("ms_per_step"), "warmup": line.get("warmup"), "steps": line.get("steps"),
+                "settled_ms_per_step": (line.get("settled") or {}).get("ms_per_step"),
+                "particles": (line.get("config") or {}).get("particles"),
+                "source": "profiles/%s/bench_%s_one_gpu.json (bench.py --gpus 1 --config ... on one MI355X)" % (rnd, cfg_name)}
+    return None
+
+
 def dist_geometry(args, world):
     """(name, lattice block, container size) of the N-GPU workload.  BASELINE.json: 4 GPUs = config 4 (C4), 8 GPUs =
     config 5 (C5); it has no 2-GPU config, so N = 2 (and every other N) is C3 replicated N times along x.
@@ -270,8 +296,9 @@ def dist_geometry(args, world):
     name = args.config or {4: "c4", 8: "c5"}.get(world, "c3")
     replicate = args.replicate or (args.config is None and world not in (1, 4, 8))
     block, size = ws.workloads.CONFIGS[name]
-    if replicate and world > 1:
-        return "%sx%d" % (name, world), (block[0] * world, block[1], block[2]), (size[0] * world, size[1], size[2])
+    copies = args.copies or (world if replicate else 1)
+    if copies > 1:
+        return "%sx%d" % (name, copies), (block[0] * copies, block[1], block[2]), (size[0] * copies, size[1], size[2])
     return name, block, size
 
 
@@ -330,17 +357,22 @@ def main():
         else:
             transport = ws.slab.TorchDistTransport(rank, world, local_rank, data_group=None, ctrl_group=ctrl)
 
-        def make_worker(ieee=False):
+        def make_worker(ieee=False, profile=True):
             return ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
                                       stream=None if which == "rccl" else torch.cuda.current_stream().cuda_stream,
-                                      profile=not args.graph, ieee_division=ieee, graph=args.graph)
+                                      profile=profile and not args.graph, ieee_division=ieee, graph=args.graph)
     else:
-        cfg_name = base_name = args.config or "c3"
-        pos, params = ws.workloads.make_workload(cfg_name, args.dist)
+        cfg_name, block, size = dist_geometry(args, 1)
+        base_name = cfg_name.split("x")[0]
+        if cfg_name == base_name:
+            pos, params = ws.workloads.make_workload(cfg_name, args.dist)
+        else:  # --copies: the geometry an N-GPU --replicate run cuts into slabs, on this one GPU
+            pos, _, _, params = ws.slab.make_dist_workload(ws, block, size, args.dist, 0, 1, seed=ws.workloads.cloud_seed(base_name))
         n_global = pos.shape[0]
 
-        def make_worker(ieee=False):
-            return ws.FluidWorker(pos, params, device=local_rank, profile=not args.graph, ieee_division=ieee, graph=args.graph)
+        def make_worker(ieee=False, profile=True):
+            return ws.FluidWorker(pos, params, device=local_rank, profile=profile and not args.graph, ieee_division=ieee,
+                                  graph=args.graph)
 
     # HIP events time only the two neighbour kernels inside the timed regions (the start / stop events each launch
     # carries, on the library's stream; a slab step that splits them into early / late ranges records events around
@@ -440,33 +472,95 @@ def main():
         i_elapsed, i_prof = timed_window(w2, args.steps)
         ieee = {"ms_per_step": i_elapsed / args.steps * 1e3, "global_steps_per_s": args.steps / i_elapsed,
                 "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in i_prof.items() if v[1]}}
+        done = args.warmup + args.steps
+        if settled is not None and done <= SETTLED_FROM:
+            # the settled window with the reference's expression tree as well (one repetition): the dense state is where
+            # correctly rounded division costs most
+            w2.run(SETTLED_FROM - done)
+            is_elapsed, is_prof = timed_window(w2, SETTLED_STEPS)
+            ieee["settled"] = {"ms_per_step": is_elapsed / SETTLED_STEPS * 1e3, "global_steps_per_s": SETTLED_STEPS / is_elapsed,
+                               "kernel_ms": {k: (v[0] / max(v[1], 1)) for k, v in is_prof.items() if v[1]}}
         w2.close()
 
     # SURVEY 8(d)'s second number: the Bevy host's per-frame pattern (src/fluid_compute.rs:478: positions read back
-    # every frame) over the same window -- id-ordered positions, 12 B/particle, into a page-locked buffer, the copy
-    # of frame k overlapped with step k + 1 (ws_read_positions_begin / ws_step / ws_read_positions_end).  PCIe
-    # inclusive, so by definition never `value`.
+    # every frame) -- id-ordered positions, 12 B/particle, into the library's own page-locked double buffer, the copy of
+    # frame k overlapped with step k + 1 (ws_read_positions_begin(h, NULL) / ws_step / ws_read_positions_end), over the
+    # same two windows.  PCIe inclusive, so by definition never `value`.  The handle has no WS_FLAG_PROFILE (no host
+    # runs its frame loop with per-kernel timing on); `ratio` = frame time / max(step alone, copy alone): 1.0 = the copy
+    # hides behind the step, or the step behind the copy, completely.
     with_readback = None
     if not args.no_readback and not distributed:
-        import numpy as np
-
-        w3 = make_worker()
+        legacy = os.environ.get("WS_BENCH_RB_VARIANT") == "r03"  # A/B: round 3's leg (profiled handle, caller's registered buffer)
+        w3 = make_worker(profile=legacy)
         w3.run(args.warmup)
-        buf = np.empty((n_global, 3), np.float32)
-        w3.pin_host_buffer(buf)
-        w3.sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            w3.read_positions_begin(buf)
-            w3.run(1)
-            w3.read_positions_end()
-        w3.sync()
-        r_elapsed = time.perf_counter() - t0
-        w3.unpin_host_buffer(buf)
+        if legacy:
+            import numpy as np
+
+            rb_buf = np.empty((n_global, 3), np.float32)
+            w3.pin_host_buffer(rb_buf)
+            w3.read_positions_begin_owned = lambda: w3.read_positions_begin(rb_buf)
+        w3.read_positions_begin_owned()  # (allocates the two page-locked buffers and the copy stream: not part of a frame)
+        w3.read_positions_end()
+
+        def frame_leg(steps, step_ms):
+            w3.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):  # the copy by itself, from this state (the state does not move)
+                w3.read_positions_begin_owned()
+                w3.read_positions_end()
+            copy_ms = (time.perf_counter() - t0) / 5 * 1e3
+            w3.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w3.read_positions_begin_owned()
+                w3.run(1)
+                w3.read_positions_end()
+            w3.sync()
+            frame_ms = (time.perf_counter() - t0) / steps * 1e3
+            return {"steps_per_s": 1e3 / frame_ms, "ms_per_frame": frame_ms, "copy_alone_ms": copy_ms, "step_alone_ms": step_ms,
+                    "ratio_to_max_of_step_and_copy": frame_ms / max(step_ms, copy_ms),
+                    "bytes_per_frame": n_global * 12, "copy_GBps": n_global * 12 / copy_ms / 1e6}
+
+        with_readback = frame_leg(args.steps, elapsed / args.steps * 1e3)
+        with_readback["pattern"] = ("per frame: ws_read_positions_begin(h, NULL) (id order, 12 B/particle, the library's "
+                                    "page-locked double buffer, SDMA copy on a stream of its own priority), ws_step, "
+                                    "ws_read_positions_end; same window as `value`; copy_alone = gather + copy + host round trip")
+        done = args.warmup + args.steps
+        if settled is not None and done <= SETTLED_FROM:
+            w3.run(SETTLED_FROM - done)
+            settled["with_readback"] = frame_leg(SETTLED_STEPS, settled["ms_per_step"])
         w3.close()
-        with_readback = {"steps_per_s": args.steps / r_elapsed, "ms_per_frame": r_elapsed / args.steps * 1e3,
-                         "pattern": "per frame: ws_read_positions_begin (id order, 12 B/particle, pinned host buffer), "
-                                    "ws_step, ws_read_positions_end; same window as `value`"}
+
+    # BASELINE.json's single-GPU target, driver-timed: ">= 10 M particles at >= 60 simulation steps/s on one MI355X".
+    # C4 (16 777 216 particles, the smallest BASELINE config above 10 M) on this one GPU, the settled window (steps
+    # 400..500 after the run-up: the slowest state of the trajectory), one repetition.
+    north_star = None
+    if not args.no_north_star and not distributed and cfg_name == "c3" and args.dist == "cloud" and not args.graph:
+        npos, nparams = ws.workloads.make_workload("c4", "cloud")
+        w4 = ws.FluidWorker(npos, nparams, device=local_rank, profile=False)
+        w4.run(10)
+        w4.sync()
+        t0 = time.perf_counter()
+        w4.run(20)
+        w4.sync()
+        early = (time.perf_counter() - t0) / 20
+        w4.run(SETTLED_FROM - 30)
+        w4.sync()
+        t0 = time.perf_counter()
+        w4.run(SETTLED_STEPS)
+        w4.sync()
+        late = (time.perf_counter() - t0) / SETTLED_STEPS
+        w4.close()
+        north_star = {"target": ">= 10 M particles at >= 60 steps/s on one MI355X (BASELINE.json north_star)",
+                      "workload": "C4: %d particles, uniform cloud seed 0x%X, one GPU" % (npos.shape[0], ws.workloads.cloud_seed("c4")),
+                      "particles": int(npos.shape[0]),
+                      "steps_per_s": 1.0 / late, "ms_per_step": late * 1e3,
+                      "window": "steps %d..%d (settled: the slowest state of the trajectory), one repetition" % (SETTLED_FROM, SETTLED_FROM + SETTLED_STEPS),
+                      "early": {"window": "steps 10..30", "steps_per_s": 1.0 / early, "ms_per_step": early * 1e3},
+                      "meets_10M_at_60": bool(npos.shape[0] >= 10_000_000 and 1.0 / late >= 60.0),
+                      "algorithmic_GBps_step": B_ALG_STEP * npos.shape[0] / late / 1e9,
+                      "frac_of_measured_copy_bw_algorithmic": B_ALG_STEP * npos.shape[0] / late / 1e9 / HBM_COPY_GBS}
+        del npos
 
     if rank == 0:
         global_steps_per_s = args.steps / elapsed
@@ -478,6 +572,13 @@ def main():
         shares = n_global / C3_PARTICLES
         dist_name = ("uniform cloud seed 0x%X" % ws.workloads.cloud_seed(base_name)) if args.dist == "cloud" \
             else "cube_fluid lattice"
+        # "scaling" is a statement about a multi-GPU run: null on one GPU.  BASELINE's C4 / C5 are FIXED problems cut into
+        # 4 / 8 slabs (strong: judged against the same problem on one GPU, `same_config_one_gpu`); a replicated config
+        # (N = 2: C3 twice along x) keeps the work per GPU (weak).
+        scaling = None if world == 1 else ("weak" if cfg_name != base_name else "strong")
+        one_gpu = same_config_one_gpu(cfg_name, args.dist) if world > 1 else None
+        if one_gpu:
+            one_gpu["same_window"] = one_gpu["warmup"] == args.warmup and one_gpu["steps"] == args.steps
         out = {
             "metric": "simulation steps/sec @ N particles",
             "value": global_steps_per_s,
@@ -487,7 +588,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -529,6 +630,19 @@ def main():
             out["ieee"] = ieee
         if with_readback is not None:
             out["with_readback"] = with_readback
+        if north_star is not None:
+            out["north_star"] = north_star
+        if world > 1:
+            # the like-for-like yard-stick of a multi-GPU run: the SAME configuration on one GPU (it fits: C5 is 27 GB),
+            # from the committed one-GPU line of that configuration.  north_star's ">= 6x at 8 GPUs" is judged on
+            # speedup_vs_one_gpu_same_config of the C5 run.
+            out["same_config_one_gpu"] = one_gpu
+            out["speedup_vs_one_gpu_same_config"] = (
+                {"first_window": one_gpu["ms_per_step"] / out["ms_per_step"] if one_gpu.get("ms_per_step") and one_gpu.get("same_window") else None,
+                 "settled": one_gpu["settled_ms_per_step"] / settled["ms_per_step"] if settled and one_gpu.get("settled_ms_per_step") else None}
+                if one_gpu else None)
+            out["c3_equivalent_note"] = ("c3_equivalent_steps_per_s compares containers of different height (C4 / C5 settle into a "
+                                         "denser floor layer than C3: +36 % / +55 % per particle on one GPU) -- not a scaling efficiency")
         if transport is not None:
             out["config"]["transport"] = type(transport).__name__
         out["stats"] = stats

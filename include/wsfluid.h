@@ -178,6 +178,13 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz);
  * until _end. */
 ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz);
 ws_status ws_read_positions_end(ws_handle *h);
+/* out_xyz == NULL in ws_read_positions_begin: the copy goes into one of TWO page-locked buffers the library owns
+ * (SURVEY 8(b) "Ownership": the library owns all pinned staging), filled alternately; after _end,
+ * ws_read_positions_view hands out the buffer the last finished readback filled.  It stays untouched until the
+ * second-next _begin(h, NULL), so update() can still scatter frame k's positions into its Transforms
+ * (src/fluid_compute.rs:483-485) while frame k+1's copy is in flight.  The copy runs on an SDMA engine, on a stream
+ * of a priority of its own (it never shares a hardware queue with the step's stream). */
+ws_status ws_read_positions_view(ws_handle *h, const float **out_xyz);
 /* `velocities.length()` per particle in ORIGINAL-ID order: n floats -- what the reference's (commented-out)
  * speed colouring system reads back 80 B per particle for (src/fluid_compute.rs:489-502).  Waits for
  * enqueued steps first. */

@@ -298,6 +298,37 @@ def test_asynchronous_readback_captures_the_state_at_begin(ws):
     w.close()
 
 
+def test_asynchronous_readback_into_the_librarys_own_buffers(ws):
+    """ws_read_positions_begin(h, NULL): the copy goes into one of two page-locked buffers the library owns; the view
+    of frame k stays untouched while frame k + 1's copy is in flight (what update() scatters into its Transforms)."""
+    pos, params = ws.workloads.make_workload("c2", "cloud")
+    w = ws.FluidWorker(pos, params)
+    with pytest.raises(ws.WsError):
+        w.read_positions_view()                  # nothing read yet
+    frames = []
+    for f in range(4):
+        w.run(2)
+        want = w.read_positions()
+        w.read_positions_begin_owned()
+        w.run(3)                                 # overlaps with the copy
+        if frames:                               # the previous frame's view is still intact while this copy runs
+            assert np.array_equal(frames[-1][0], frames[-1][1])
+        w.read_positions_end()
+        view = w.read_positions_view()
+        assert np.array_equal(view, want)
+        frames.append((view, want))
+    assert frames[-1][0].ctypes.data != frames[-2][0].ctypes.data  # two buffers, alternately
+    assert frames[-1][0].ctypes.data == frames[-3][0].ctypes.data
+    # a caller buffer in between does not disturb the owned pair; the runtime's copy path gives the same bytes
+    buf = np.empty((pos.shape[0], 3), np.float32)
+    want = w.read_positions()
+    w.read_positions_begin(buf)                  # pageable: hipMemcpyAsync
+    w.read_positions_end()
+    assert np.array_equal(buf, want)
+    assert np.array_equal(w.read_positions_view(), frames[-1][1])
+    w.close()
+
+
 def test_readback_into_an_explicitly_pinned_buffer(ws):
     """update() reads into the same host buffer every frame; the host may page-lock it (PCIe-rate copy).
     The data must not depend on the copy path."""

@@ -58,3 +58,7 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     assert abs(line["c3_equivalent_steps_per_s"] - shares * line["value"]) < 1e-9 * line["value"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert line["settled"] is not None and line["settled"]["steps"] == 100 and line["settled"]["warmup"] == 400
+    # the like-for-like yard-stick of a multi-GPU line (no one-GPU file is committed for this toy geometry: null, but there)
+    assert {"same_config_one_gpu", "speedup_vs_one_gpu_same_config", "c3_equivalent_note"} <= set(line)
+    assert line["same_config_one_gpu"] is None and line["speedup_vs_one_gpu_same_config"] is None
+    assert "north_star" not in line and line["roofline"]["priced_against"].startswith("hbm")

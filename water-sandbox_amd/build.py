@@ -68,6 +68,24 @@ def build_refcheck_library(force=False, verbose=False):
     return _compile(REFCHECK_LIB, ["-DWS_WITH_REFCHECK", "-I", REFCHECK_DIR], verbose)
 
 
+# TEST-ONLY: a stand-in for librccl (tests/fake_rccl/) whose "ranks" are host threads of one process on one GPU, so that
+# a one-GPU box can drive csrc/ws_rccl.cpp with real peers.  Loaded only when WS_RCCL_LIBRARY names it.
+FAKE_RCCL_SRC = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.hip")
+FAKE_RCCL_LIB = os.path.join(ROOT, "tests", "libfakerccl.so")
+
+
+def build_fake_rccl(force=False, verbose=False):
+    if not force and os.path.exists(FAKE_RCCL_LIB) and os.path.getmtime(FAKE_RCCL_LIB) >= os.path.getmtime(FAKE_RCCL_SRC):
+        return FAKE_RCCL_LIB
+    cmd = [hipcc(), "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", FAKE_RCCL_LIB,
+           FAKE_RCCL_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return FAKE_RCCL_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
     print(build_refcheck_library(force=True, verbose=True))
+    print(build_fake_rccl(force=True, verbose=True))

@@ -531,6 +531,8 @@ void free_all(ws_handle *h)
     if (h->rb_gathered) hipEventDestroy(h->rb_gathered);
     if (h->rb_done) hipEventDestroy(h->rb_done);
     hipFree(h->rb_stage);
+    for (float *b : h->rb_host)
+        if (b) hipHostFree(b);
     drain_profile(h);
     for (auto e : h->pool) hipEventDestroy(e);
     free_grid(h);
@@ -911,19 +913,46 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 }
 
 // The frame loop's readback, overlapped with the next step: `begin` enqueues the id-order gather behind the steps
-// enqueued so far (a ~20 us kernel on the library's stream) and starts the device->host copy on a separate copy
+// enqueued so far (a ~65 us kernel on the library's stream) and starts the device->host copy on a separate copy
 // stream; steps enqueued after `begin` run while the copy is in flight; `end` waits for the copy alone.
+// out_xyz == NULL: into one of two page-locked buffers the library owns, alternately (ws_read_positions_view).
 ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
 {
-    if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
+    if (!h) return WS_ERR_INVALID_ARG;
     WS_REF_DISPATCH(h, fail(h, WS_ERR_UNSUPPORTED, "no asynchronous readback in the reference-order validation mode"));
     if (h->rb_inflight) return fail(h, WS_ERR_INVALID_ARG, "a readback is already in flight (call ws_read_positions_end)");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)(h->slab ? h->slab->n_global : h->n) * 12;
     if (!h->copy_stream) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        // A stream of another PRIORITY than the step's: the runtime multiplexes the streams of one priority onto a few
+        // hardware queues (round-robin, 4 by default), and a copy stream that lands on the step stream's queue puts its
+        // wait-for-the-copy barrier in front of the next step's kernels -- copy and step then run in series.  Queues
+        // are pooled per priority, so this stream can never share one with the step.
+        int lo = 0, hi = 0;
+        const char *pr = getenv("WS_COPY_STREAM_PRIORITY");  // "default" = same priority as the step's stream (A/B runs)
+        if (pr && strcmp(pr, "default") == 0) {
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        } else {
+            HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (numerically lowest = highest priority)
+            HIP_TRY(h, hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, hi));
+        }
         HIP_TRY(h, hipEventCreateWithFlags(&h->rb_gathered, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&h->rb_done, hipEventDisableTiming));
+    }
+    const bool owned = out_xyz == nullptr;
+    if (owned) {
+        if (h->rb_host_bytes < bytes) {
+            for (float *&b : h->rb_host) {
+                if (b) hipHostFree(b);
+                b = nullptr;
+            }
+            h->rb_host_bytes = 0;
+            h->rb_last = -1;
+            for (float *&b : h->rb_host) HIP_TRY(h, hipHostMalloc((void **)&b, bytes, hipHostMallocDefault));
+            h->rb_host_bytes = bytes;
+        }
+        h->rb_fill = h->rb_last == 0 ? 1 : 0;  // never the buffer the host may still be reading
+        out_xyz = h->rb_host[h->rb_fill];
     }
     const float *src;
     if (h->slab) {
@@ -946,9 +975,14 @@ ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
     }
     HIP_TRY(h, hipEventRecord(h->rb_gathered, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->rb_gathered, 0));
+    // hipMemcpyAsync, i.e. an SDMA engine: it reads HBM and writes PCIe beside the shader's memory path.  (Measured in
+    // round 4, profiles/r04/readback: a copy KERNEL storing into the mapped host buffer -- even one of only 64 workgroups
+    // -- slows the step's short bandwidth-bound kernels while it runs, k_scan 21 -> 170-560 us, k_place 31 -> 220-590 us;
+    // the runtime's own blit kernel, which it substitutes for SDMA whenever a profiler is attached, does the same.)
     HIP_TRY(h, hipMemcpyAsync(out_xyz, src, bytes, hipMemcpyDeviceToHost, h->copy_stream));
     HIP_TRY(h, hipEventRecord(h->rb_done, h->copy_stream));
     h->rb_inflight = true;
+    h->rb_owned = owned;
     return WS_OK;
 }
 
@@ -959,6 +993,16 @@ ws_status ws_read_positions_end(ws_handle *h)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipEventSynchronize(h->rb_done));
     h->rb_inflight = false;
+    if (h->rb_owned) h->rb_last = h->rb_fill;
+    return WS_OK;
+}
+
+ws_status ws_read_positions_view(ws_handle *h, const float **out_xyz)
+{
+    if (!h || !out_xyz) return WS_ERR_INVALID_ARG;
+    *out_xyz = nullptr;
+    if (h->rb_last < 0) return fail(h, WS_ERR_INVALID_ARG, "no finished readback into the library's buffers (ws_read_positions_begin(h, NULL) / _end)");
+    *out_xyz = h->rb_host[h->rb_last];
     return WS_OK;
 }
 

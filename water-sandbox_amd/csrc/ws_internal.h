@@ -189,6 +189,11 @@ struct ws_handle {
     float *rb_stage = nullptr;
     size_t rb_bytes = 0;
     bool rb_inflight = false;
+    // ws_read_positions_begin(h, NULL): two page-locked buffers the library owns, filled alternately
+    float *rb_host[2] = {nullptr, nullptr};
+    size_t rb_host_bytes = 0;
+    int rb_fill = 0, rb_last = -1;  // the buffer the readback in flight fills; the one the last finished readback filled
+    bool rb_owned = false;          // the readback in flight goes into rb_host[rb_fill]
 
     // reference-layout sort view (lazy)
     uint32_t *v_keys = nullptr, *v_perm = nullptr, *v_tmp = nullptr, *v_count = nullptr,

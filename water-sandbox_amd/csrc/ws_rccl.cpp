@@ -50,9 +50,16 @@ bool sym(F &fn, const char *name)
 bool load_rccl()
 {
     std::call_once(g_once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            g_api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (g_api.lib) break;
+        // WS_RCCL_LIBRARY: another library with RCCL's interface, by path (a site's own build; the test suite's
+        // one-process stand-in, tests/fake_rccl/).  Never a default: unset, only librccl is looked for.
+        const char *override_path = getenv("WS_RCCL_LIBRARY");
+        if (override_path && *override_path) {
+            g_api.lib = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                g_api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (g_api.lib) break;
+            }
         }
         if (!g_api.lib) {
             g_api.error = std::string("cannot load librccl: ") + dlerror();

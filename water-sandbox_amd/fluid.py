@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ws_default_params", "ws_get_smoothing_kernel", "ws_cube_fluid", "ws_get_ext",
     "ws_bit_sorter_stage_count", "ws_status_string", "ws_abi_version", "ws_create", "ws_destroy",
     "ws_step", "ws_ready", "ws_sync", "ws_set_params", "ws_read_positions", "ws_read_particles",
-    "ws_reset", "ws_write_particles", "ws_pin_host_buffer", "ws_unpin_host_buffer", "ws_read_speeds", "ws_read_positions_begin", "ws_read_positions_end", "ws_slab_counters", "ws_rccl_unique_id", "ws_rccl_transport_create",
+    "ws_reset", "ws_write_particles", "ws_pin_host_buffer", "ws_unpin_host_buffer", "ws_read_speeds", "ws_read_positions_begin", "ws_read_positions_end", "ws_read_positions_view", "ws_slab_counters", "ws_rccl_unique_id", "ws_rccl_transport_create",
     "ws_rccl_transport_destroy", "ws_rccl_last_error", "ws_rccl_transport_communicators",
     "ws_local_hub_create", "ws_local_hub_destroy", "ws_local_transport_create", "ws_local_transport_destroy", "ws_read_sort_view", "ws_last_error", "ws_num_particles",
     "ws_steps_done", "ws_kernel_name", "ws_profile_read", "ws_profile_reset", "ws_profile_select",
@@ -135,6 +135,7 @@ def bind_library(path):
     L.ws_read_speeds.argtypes = [vp, vp]
     L.ws_read_positions_begin.argtypes = [vp, vp]
     L.ws_read_positions_end.argtypes = [vp]
+    L.ws_read_positions_view.argtypes = [vp, C.POINTER(vp)]
     L.ws_unpin_host_buffer.argtypes = [vp, vp]
     L.ws_write_particles.argtypes = [vp, vp]
     L.ws_read_sort_view.argtypes = [vp, vp, vp, vp]
@@ -275,6 +276,18 @@ class FluidWorker:
 
     def read_positions_end(self):
         self._check(self._L.ws_read_positions_end(self._h))
+
+    def read_positions_begin_owned(self):
+        """The same into one of the two page-locked buffers the library owns (ws_read_positions_begin(h, NULL))."""
+        self._check(self._L.ws_read_positions_begin(self._h, None))
+
+    def read_positions_view(self, n=None):
+        """(n, 3) float32 view of the library-owned buffer the last finished readback filled (no copy; valid until
+        the second-next read_positions_begin_owned)."""
+        p = C.c_void_p()
+        self._check(self._L.ws_read_positions_view(self._h, C.byref(p)))
+        n = self.n if n is None else n
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n, 3))
 
     def read_speeds(self):
         """|velocity| per particle in original-id order (the reference's speed colouring input)."""
