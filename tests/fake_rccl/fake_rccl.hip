@@ -7,8 +7,8 @@
 // What it keeps from the real thing, because the tests are about exactly that:
 //   * every call is STREAM-ORDERED and returns at once -- no host wait, no stream synchronisation, no allocation, so a
 //     call may sit inside hipStreamBeginCapture .. hipStreamEndCapture and be replayed from a hipGraph;
-//   * ranks synchronise ON THE DEVICE, by flags in memory (a one-thread wait kernel in front of the copy, a one-thread
-//     publish kernel behind it), as RCCL's kernels do -- never through events shared between two ranks' streams, which
+//   * ranks synchronise ON THE DEVICE, by flags in memory that the copy kernels themselves wait for and raise, as RCCL's
+//     kernels do -- never through events shared between two ranks' streams, which
 //     two separately captured graphs could not share;
 //   * every sequence number lives in device memory and is advanced by the publish kernels, so a replayed graph finds
 //     the right one;
@@ -37,50 +37,127 @@ enum { OK = 0, UNHANDLED = 1, SYSTEM = 2, INTERNAL = 3, INVALID_ARG = 4, INVALID
 enum { ERR_TIMEOUT = 1u, ERR_SIZE = 2u };
 
 // control words of one directed channel (fine-grained device memory, touched with agent-scope atomics only)
-enum { C_SENT = 0, C_CONSUMED, C_SSEQ, C_RSEQ, C_BYTES, C_WORDS = 8 };
+enum { C_SENT = 0, C_CONSUMED, C_SSEQ, C_RSEQ, C_BYTES, C_WGDONE, C_WGDONE_R, C_WORDS = 8 };
 // control words of the all-gather
 enum { A_ARRIVED = 0, A_DEPARTED, A_WORDS = 4 };
 
 __device__ __forceinline__ uint32_t ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// spin until (int)(*flag - (*mine * mul + add)) >= 0, for at most `ticks` of the 100 MHz wall clock; an error word that
-// is already set ends every wait at once (the failure drains instead of costing one timeout per call)
-__global__ void fk_wait(const uint32_t *flag, const uint32_t *mine, uint32_t mul, uint32_t add, uint32_t *err, unsigned long long ticks)
+// Every nccl operation is ONE kernel of NB workgroups (all resident at once; every wait in them is bounded): the
+// workgroups wait for the flag themselves, copy, and the last one to finish publishes -- so the only ordering the
+// stand-in asks of the runtime is that of whole kernels in one stream.  (Earlier versions used separate wait / copy /
+// publish kernels, or hipMemcpyAsync for the payload, and delivered stale bytes now and then: the flags of two ranks
+// order their copies with no event or barrier packet the runtime knows of, so nothing made one kernel's stores reach
+// memory before the next kernel of the stream raised the flag.)
+#define NB 64
+#define NT 256
+
+// thread 0: spin until (int)(*flag - target) >= 0; false after a time-out (error word set) or if the error word is set
+__device__ bool fk_spin(const uint32_t *flag, uint32_t target, uint32_t *err, unsigned long long ticks)
 {
-    const uint32_t target = ld(mine) * mul + add;
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        if ((int32_t)(ld(flag) - target) >= 0) break;
-        if (ld(err)) break;
+        if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return true;
+        if (ld(err)) return false;
         if (wall_clock64() - t0 > ticks) {
             __hip_atomic_fetch_or(err, ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+            return false;
         }
         __builtin_amdgcn_s_sleep(8);
     }
-    __threadfence();
 }
-// the sender's publish: *seq += 1, the message's size, then the flag
-__global__ void fk_publish(uint32_t *seq, uint32_t *flag, uint32_t *bytes_word, uint32_t bytes)
+// every wave's stores performed at agent scope, then: is this the last workgroup of the kernel to get here?
+__device__ bool fk_last(uint32_t *wg_done)
 {
-    __threadfence();
-    const uint32_t s = ld(seq) + 1u;
-    st(seq, s);
-    if (bytes_word) st(bytes_word, bytes);
-    __threadfence();
-    st(flag, s);
+    __shared__ uint32_t s_last;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(wg_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = done + 1u == gridDim.x ? 1u : 0u;
+        if (s_last) st(wg_done, 0u);
+    }
+    __syncthreads();
+    return s_last != 0u;
 }
-// the receiver's check of the size the sender published (in front of its copy)
-__global__ void fk_check(const uint32_t *bytes_word, uint32_t bytes, uint32_t *err)
+__device__ void fk_copy(uint32_t *dst, const uint32_t *src, size_t nwords, bool dst_is_staging)
 {
-    if (!ld(err) && ld(bytes_word) != bytes) __hip_atomic_fetch_or(err, ERR_SIZE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // EVERY wave acquires at agent scope before it reads the staging buffer (thread 0's acquire on the flag invalidates
+    // its own wave's view only): without it a wave now and then got the bytes of the same address from two rounds ago
+    // out of its XCD's L2 -- the product's look-back scan survives such reads because it retries, a copy does not
+    if (!dst_is_staging) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (size_t i = blockIdx.x * (size_t)NT + threadIdx.x; i < nwords; i += (size_t)NB * NT) {
+        if (dst_is_staging) st(dst + i, src[i]);
+        else dst[i] = ld(src + i);
+    }
 }
-__global__ void fk_count(uint32_t *counter, uint32_t *seq)
+
+// ncclSend: the staging buffer is free once the receiver has consumed everything sent so far
+__global__ void __launch_bounds__(NT) fk_send(const uint32_t *__restrict__ src, uint32_t *staging, size_t nwords, uint32_t *ctl, uint32_t bytes,
+                                              uint32_t *err, unsigned long long ticks)
 {
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) s_ok = fk_spin(ctl + C_CONSUMED, ld(ctl + C_SSEQ), err, ticks) ? 1u : 0u;
+    __syncthreads();
+    if (s_ok) fk_copy(staging, src, nwords, true);
+    if (!fk_last(ctl + C_WGDONE) || threadIdx.x != 0) return;
+    const uint32_t sq = ld(ctl + C_SSEQ) + 1u;
+    st(ctl + C_SSEQ, sq);
+    st(ctl + C_BYTES, bytes);
     __threadfence();
-    if (seq) st(seq, ld(seq) + 1u);
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctl + C_SENT, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ncclRecv
+__global__ void __launch_bounds__(NT) fk_recv(uint32_t *__restrict__ dst, const uint32_t *staging, size_t nwords, uint32_t *ctl, uint32_t bytes,
+                                              uint32_t *err, unsigned long long ticks)
+{
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) {
+        uint32_t ok = fk_spin(ctl + C_SENT, ld(ctl + C_RSEQ) + 1u, err, ticks) ? 1u : 0u;
+        if (ok && ld(ctl + C_BYTES) != bytes) __hip_atomic_fetch_or(err, ERR_SIZE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (s_ok) fk_copy(dst, staging, nwords, false);
+    if (!fk_last(ctl + C_WGDONE_R) || threadIdx.x != 0) return;
+    const uint32_t rq = ld(ctl + C_RSEQ) + 1u;
+    st(ctl + C_RSEQ, rq);
+    __threadfence();
+    __hip_atomic_store(ctl + C_CONSUMED, rq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ncclAllGather, round k of this rank (k = *seq): every rank has left round k - 1 (departed >= W k) -> my part in ->
+// arrived += 1 -> all W have arrived (arrived >= W (k + 1)) and brought the same byte count -> everything out ->
+// departed += 1, *seq = k + 1
+__global__ void __launch_bounds__(NT) fk_allgather(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t *staging, size_t nwords_each,
+                                                   uint32_t rank, uint32_t W, uint32_t *ag_ctl, uint32_t *seq, uint32_t *notes, uint32_t *wg_in,
+                                                   uint32_t *wg_out, uint32_t bytes, uint32_t *err, unsigned long long ticks)
+{
+    __shared__ uint32_t s_ok, s_round;
+    if (threadIdx.x == 0) {
+        s_round = ld(seq);
+        s_ok = fk_spin(ag_ctl + A_DEPARTED, s_round * W, err, ticks) ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t round = s_round;
+    if (s_ok) fk_copy(staging + (size_t)rank * nwords_each, src, nwords_each, true);
+    if (fk_last(wg_in) && threadIdx.x == 0) {
+        st(notes + rank, bytes);
+        __threadfence();
+        __hip_atomic_fetch_add(ag_ctl + A_ARRIVED, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t ok = fk_spin(ag_ctl + A_ARRIVED, round * W + W, err, ticks) ? 1u : 0u;
+        for (uint32_t r = 0; ok && r < W; r++)
+            if (ld(notes + r) != bytes) __hip_atomic_fetch_or(err, ERR_SIZE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (s_ok) fk_copy(dst, staging, nwords_each * W, false);
+    if (!fk_last(wg_out) || threadIdx.x != 0) return;
+    st(seq, round + 1u);
+    __threadfence();
+    __hip_atomic_fetch_add(ag_ctl + A_DEPARTED, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct Channel {
@@ -92,6 +169,8 @@ struct Group {
     int world = 0, joined = 0, left = 0;
     std::vector<Channel> to_right, to_left;  // [r]: r -> r + 1 / r -> r - 1
     uint32_t *ag_ctl = nullptr, *ag_seq = nullptr;  // all-gather: arrival / departure counters, one round counter per rank
+    uint32_t *ag_cnt = nullptr;                    // ... and the byte count every rank brought to the current round
+    uint32_t *ag_wg = nullptr, *ag_wg2 = nullptr;  // ... and workgroup counters per rank (the copy kernels' last-workgroup test)
     char *ag_staging = nullptr;
     uint32_t *err = nullptr;
     size_t chan_cap = 0, ag_cap = 0;
@@ -141,12 +220,15 @@ bool group_alloc(Group *g, int world)
     g->err = (uint32_t *)fine(64);
     g->ag_ctl = (uint32_t *)fine(A_WORDS * 4);
     g->ag_seq = (uint32_t *)fine((size_t)world * 4);
-    if (!g->err || !g->ag_ctl || !g->ag_seq || hipMalloc(&g->ag_staging, g->ag_cap) != hipSuccess) return false;
+    g->ag_cnt = (uint32_t *)fine((size_t)world * 4);
+    g->ag_wg = (uint32_t *)fine((size_t)world * 4);
+    g->ag_wg2 = (uint32_t *)fine((size_t)world * 4);
+    if (!g->err || !g->ag_ctl || !g->ag_seq || !g->ag_cnt || !g->ag_wg || !g->ag_wg2 || !(g->ag_staging = (char *)fine(g->ag_cap))) return false;
     for (int r = 0; r < world; r++)
         for (Channel *c : {r + 1 < world ? &g->to_right[r] : nullptr, r > 0 ? &g->to_left[r] : nullptr}) {
             if (!c) continue;
             c->ctl = (uint32_t *)fine(C_WORDS * 4);
-            if (!c->ctl || hipMalloc(&c->staging, g->chan_cap) != hipSuccess) return false;
+            if (!c->ctl || !(c->staging = (char *)fine(g->chan_cap))) return false;
         }
     return hipDeviceSynchronize() == hipSuccess;
 }
@@ -161,6 +243,9 @@ void group_free(Group *g)
         }
     hipFree(g->ag_ctl);
     hipFree(g->ag_seq);
+    hipFree(g->ag_cnt);
+    hipFree(g->ag_wg);
+    hipFree(g->ag_wg2);
     hipFree(g->ag_staging);
     hipFree(g->err);
     delete g;
@@ -209,19 +294,14 @@ int issue(const PendingOp &op)
     Group *g = op.comm->g;
     const int me = op.comm->rank;
     Channel *c = op.send ? channel(g, me, op.peer) : channel(g, op.peer, me);
-    if (!c || op.bytes > g->chan_cap || op.bytes >= ((size_t)1 << 32)) return INVALID_ARG;
+    if (!c || op.bytes > g->chan_cap || op.bytes >= ((size_t)1 << 32) || (op.bytes & 3u)) return INVALID_ARG;
     hipStream_t s = op.stream;
-    if (op.send) {
-        // the staging buffer is free once the receiver has consumed everything sent so far
-        hipLaunchKernelGGL(fk_wait, dim3(1), dim3(1), 0, s, c->ctl + C_CONSUMED, c->ctl + C_SSEQ, 1u, 0u, g->err, g->ticks);
-        if (hipMemcpyAsync(c->staging, op.ptr, op.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return UNHANDLED;
-        hipLaunchKernelGGL(fk_publish, dim3(1), dim3(1), 0, s, c->ctl + C_SSEQ, c->ctl + C_SENT, c->ctl + C_BYTES, (uint32_t)op.bytes);
-    } else {
-        hipLaunchKernelGGL(fk_wait, dim3(1), dim3(1), 0, s, c->ctl + C_SENT, c->ctl + C_RSEQ, 1u, 1u, g->err, g->ticks);
-        hipLaunchKernelGGL(fk_check, dim3(1), dim3(1), 0, s, c->ctl + C_BYTES, (uint32_t)op.bytes, g->err);
-        if (hipMemcpyAsync(op.ptr, c->staging, op.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return UNHANDLED;
-        hipLaunchKernelGGL(fk_publish, dim3(1), dim3(1), 0, s, c->ctl + C_RSEQ, c->ctl + C_CONSUMED, (uint32_t *)nullptr, 0u);
-    }
+    if (op.send)
+        hipLaunchKernelGGL(fk_send, dim3(NB), dim3(NT), 0, s, (const uint32_t *)op.ptr, (uint32_t *)c->staging, op.bytes / 4, c->ctl,
+                           (uint32_t)op.bytes, g->err, g->ticks);
+    else
+        hipLaunchKernelGGL(fk_recv, dim3(NB), dim3(NT), 0, s, (uint32_t *)op.ptr, (const uint32_t *)c->staging, op.bytes / 4, c->ctl,
+                           (uint32_t)op.bytes, g->err, g->ticks);
     return hipGetLastError() == hipSuccess ? OK : UNHANDLED;
 }
 
@@ -350,20 +430,14 @@ int ncclAllGather(const void *sendbuf, void *recvbuf, size_t count, int dtype, v
     if (dtype != 1 || !c) return INVALID_ARG;
     Group *g = c->g;
     const uint32_t W = (uint32_t)g->world;
-    if (count * W > g->ag_cap) return INVALID_ARG;
+    if (count * W > g->ag_cap || (count & 3u)) return INVALID_ARG;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         calls()[1]++;
     }
-    uint32_t *seq = g->ag_seq + c->rank;
-    // round k of this rank: every rank has left round k - 1 (departed >= W k) -> write my part -> arrive -> all W have
-    // arrived (arrived >= W (k + 1)) -> read everything -> depart, round counter + 1
-    hipLaunchKernelGGL(fk_wait, dim3(1), dim3(1), 0, s, g->ag_ctl + A_DEPARTED, seq, W, 0u, g->err, g->ticks);
-    if (hipMemcpyAsync(g->ag_staging + (size_t)c->rank * count, sendbuf, count, hipMemcpyDeviceToDevice, s) != hipSuccess) return UNHANDLED;
-    hipLaunchKernelGGL(fk_count, dim3(1), dim3(1), 0, s, g->ag_ctl + A_ARRIVED, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(fk_wait, dim3(1), dim3(1), 0, s, g->ag_ctl + A_ARRIVED, seq, W, W, g->err, g->ticks);
-    if (hipMemcpyAsync(recvbuf, g->ag_staging, count * W, hipMemcpyDeviceToDevice, s) != hipSuccess) return UNHANDLED;
-    hipLaunchKernelGGL(fk_count, dim3(1), dim3(1), 0, s, g->ag_ctl + A_DEPARTED, seq);
+    hipLaunchKernelGGL(fk_allgather, dim3(NB), dim3(NT), 0, s, (const uint32_t *)sendbuf, (uint32_t *)recvbuf, (uint32_t *)g->ag_staging, count / 4,
+                       (uint32_t)c->rank, W, g->ag_ctl, g->ag_seq + c->rank, g->ag_cnt, g->ag_wg + c->rank, g->ag_wg2 + c->rank, (uint32_t)count,
+                       g->err, g->ticks);
     return hipGetLastError() == hipSuccess ? OK : UNHANDLED;
 }
 

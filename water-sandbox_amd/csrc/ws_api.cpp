@@ -52,6 +52,16 @@ ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipS
     } while (0)
 
 // Rust f32::powi -> llvm.powi -> compiler-rt __powisf2 (square-and-multiply).
+// A host <-> device copy on the HANDLE'S OWN stream, complete on return.  Never the legacy (null) stream: it
+// synchronises implicitly with streams that are none of this handle's business, and it fails outright
+// (hipErrorStreamCaptureImplicit) while any other thread of the host is capturing a hipGraph -- another handle with
+// WS_FLAG_GRAPH, the host's own graphs.  Ordered behind whatever the handle has enqueued.
+hipError_t copy_now(ws_handle *h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+}
+
 float powi_f32(float a, int b)
 {
     float r = 1.0f;
@@ -252,7 +262,7 @@ ws_status upload_mult(ws_handle *h)
             }
     h->alias = alias;
     if (!h->mult) HIP_TRY(h, hipMalloc(&h->mult, 32));
-    HIP_TRY(h, hipMemcpy(h->mult, m, 27, hipMemcpyHostToDevice));
+    HIP_TRY(h, copy_now(h, h->mult, m, 27, hipMemcpyHostToDevice));
     return WS_OK;
 }
 
@@ -781,7 +791,10 @@ ws_status ws_step(ws_handle *h)
     if ((h->flags & WS_FLAG_GRAPH) && !h->graph_failed && h->pred_stale) {
         if (!h->graph_exec) {
             hipGraph_t gr = nullptr;
-            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+            // (relaxed mode: a host may drive several handles from several threads -- in-process slabs, or simply two fluids --
+            // and in the other modes one thread's capture makes ANOTHER thread's legacy-stream hipMemcpy fail with
+            // hipErrorStreamCaptureImplicit; this thread itself issues nothing but launches, events and async copies here)
+            hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
             if (e == hipSuccess) {
                 enqueue_step(h);
                 e = hipStreamEndCapture(s, &gr);
@@ -1115,7 +1128,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         HIP_TRY(h, hipMalloc(&h->v_off, (size_t)n * 4));
         HIP_TRY(h, hipMalloc(&h->v_bsum, (size_t)wsk_scan_state_words(n) * 4));
         HIP_TRY(h, hipMemsetAsync(h->v_bsum, 0, (size_t)wsk_scan_state_words(n) * 4, h->stream));
-        HIP_TRY(h, hipMemcpy(h->v_start + n, &n, 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, copy_now(h, h->v_start + n, &n, 4, hipMemcpyHostToDevice));
     }
     if (!stepped) {
         // src/fluid_compute.rs:306-308: all three buffers start as the identity
@@ -1124,7 +1137,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipStreamSynchronize(s));
         for (uint32_t *dst : {keys_by_id, perm, cell_offsets})
-            if (dst) HIP_TRY(h, hipMemcpy(dst, h->v_keys, (size_t)n * 4, hipMemcpyDeviceToHost));
+            if (dst) HIP_TRY(h, copy_now(h, dst, h->v_keys, (size_t)n * 4, hipMemcpyDeviceToHost));
         return WS_OK;
     }
     HIP_TRY(h, hipMemsetAsync(h->v_count, 0, (size_t)n * 4, s));
@@ -1144,9 +1157,9 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
     wsk_view_offsets(s, h->v_start, h->v_off, n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
-    if (keys_by_id) HIP_TRY(h, hipMemcpy(keys_by_id, keys, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (perm) HIP_TRY(h, hipMemcpy(perm, h->v_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (cell_offsets) HIP_TRY(h, hipMemcpy(cell_offsets, h->v_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (keys_by_id) HIP_TRY(h, copy_now(h, keys_by_id, keys, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (perm) HIP_TRY(h, copy_now(h, perm, h->v_perm, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (cell_offsets) HIP_TRY(h, copy_now(h, cell_offsets, h->v_off, (size_t)n * 4, hipMemcpyDeviceToHost));
     return WS_OK;
 }
 
@@ -1187,7 +1200,7 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
     if (!h || !out) return WS_ERR_INVALID_ARG;
     ws_status st = ws_sync(h);
     if (st) return st;
-    HIP_TRY(h, hipMemcpy(out, h->stats, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(h, copy_now(h, out, h->stats, 64, hipMemcpyDeviceToHost));
     for (int c = 0; c < 3; c++) out[1 + c] = (uint32_t)h->dev.cm[c];  // reference cells merged per grid cell (host-side)
     out[4] = (uint32_t)(h->slab ? h->slab->graph_steps : h->graph_steps);  // steps replayed from a captured graph
     return WS_OK;

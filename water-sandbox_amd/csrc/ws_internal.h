@@ -261,6 +261,7 @@ struct WsSlab {
     uint32_t *cnt_send = nullptr, *cnt_all = nullptr;
     uint32_t *g_send = nullptr, *g_all = nullptr, *g_out = nullptr;
     size_t g_send_bytes = 0, g_all_bytes = 0, g_out_bytes = 0;
+    std::vector<uint32_t *> retired;  // outgrown gather buffers (freed with the handle: ws_slab.inc slab_grow)
     std::vector<uint32_t> counts;     // owned particles per rank as of the last gather
     uint32_t failed = 0;              // sticky WS_DYN_ERR_* bits seen on any rank
     bool comm_failed = false;         // a transport call failed: the handle is dead
@@ -315,6 +316,7 @@ void wsk_view_fix(hipStream_t s, const uint32_t *tmp, const uint32_t *keys, cons
                   uint32_t *perm, uint32_t n);
 void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint32_t n);
 void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n);
+void wsk_set_words4(hipStream_t s, uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d);
 // slabs
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cur, uint32_t *count);
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,

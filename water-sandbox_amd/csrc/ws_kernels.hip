@@ -1501,6 +1501,22 @@ void wsk_view_offsets(hipStream_t s, const uint32_t *start, uint32_t *off, uint3
     hipLaunchKernelGGL(k_view_offsets, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, start, off, n);
 }
 
+// four words from the host into device memory BY A KERNEL (arguments, not a copy): what a transport then reads -- a
+// kernel of RCCL's, on the same stream -- was written by the kernel in front of it, the one ordering every runtime fences.
+// (A small host-to-device copy may go through the CPU's window into device memory; round 4's stand-in for librccl read
+// the previous call's words out of the L2 behind it now and then.)
+__global__ void k_set_words4(uint32_t *__restrict__ p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    p[0] = a;
+    p[1] = b;
+    p[2] = c;
+    p[3] = d;
+}
+void wsk_set_words4(hipStream_t s, uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    hipLaunchKernelGGL(k_set_words4, dim3(1), dim3(1), 0, s, p, a, b, c, d);
+}
+
 __global__ void __launch_bounds__(WS_BLOCK) k_iota(uint32_t *__restrict__ p, uint32_t n)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
