@@ -165,7 +165,13 @@ ws_status ws_ready(ws_handle *h, int *ready);
 ws_status ws_sync(ws_handle *h);
 /* The three worker.write calls of update() (src/fluid_compute.rs:479-481):
  * fluid_props, smoothing_kernel (re-derived here) and gravity; the container is
- * taken too (the reference uploads it once, :302).  Takes effect at the next ws_step. */
+ * taken too (the reference uploads it once, :302).  Takes effect at the next ws_step.
+ * Errors: WS_ERR_INVALID_ARG / WS_ERR_OUT_OF_MEMORY from the checks made BEFORE anything is touched (a radius <= 0, a
+ * grid beyond the cell budget, on slab handles a slab whose share of the fluid on the new grid exceeds its capacity --
+ * decided from the gathered state for every rank alike): the handle keeps its previous parameters and goes on.  A new
+ * smoothing radius or container rebuilds the cell tables; an allocation that fails AFTER the old ones were given up
+ * leaves the handle dead -- every later ws_step returns WS_ERR_HIP with the reason -- never half-built tables under
+ * a handle that still steps. */
 ws_status ws_set_params(ws_handle *h, const ws_params *params);
 /* worker.read_vec::<FluidParticle>("particles") followed by `.position.xyz()` per
  * label (src/fluid_compute.rs:478,:483-485): n*3 floats in ORIGINAL-ID order.
@@ -306,11 +312,15 @@ ws_status ws_slab_read_particles(ws_handle *h, ws_particle80 *out, uint32_t *out
  * particles are redistributed like on a re-grid and the run continues bit-identically to a single handle.  Cheap
  * when nothing needs to move (one gather; every rank decides alike). */
 ws_status ws_slab_rebalance(ws_handle *h);
+/* (After a re-cut, a later ws_set_params that rebuilds the grid re-applies the equal-COUNT rule on the new grid instead of
+ * falling back to equal layers.  After any load of a slab handle -- ws_reset, ws_write_particles, a re-grid, a re-cut --
+ * the 80-byte record view reports zero density / pressure / acceleration until the next ws_step, as a freshly created
+ * handle does; a single-GPU handle keeps the last step's values over a re-grid.) */
 /* Host-only: the cuts ws_slab_rebalance chooses for an x-layer histogram (hist[nx] particles per cell layer; cuts_out holds
  * world_size + 1 entries, cuts_out[0] = 0, cuts_out[world_size] = nx, strictly increasing). */
 ws_status ws_slab_balanced_cuts(const uint32_t *hist, uint32_t nx, uint32_t world_size, uint32_t *cuts_out);
-/* Migration counters of this slab since it was created, as of the last migration that has run (waits for enqueued
- * steps): out[0] = particles owned now, out[1] = particles that left, out[2] = particles that arrived, out[3] = of
+/* Migration counters of this slab since it was created (cumulative over ws_reset, ws_write_particles, a re-grid and a
+ * re-cut), as of the last migration that has run (waits for enqueued steps): out[0] = particles owned now, out[1] = particles that left, out[2] = particles that arrived, out[3] = of
  * those that left, the ones that crossed more than one slab in a step (the all-gathered route).  The reference is a
  * single-GPU program and has no counterpart; diagnostics for the host and for the tests. */
 ws_status ws_slab_counters(ws_handle *h, uint64_t out[4]);

@@ -292,6 +292,8 @@ fn update(
     // the three worker.write calls, :479-481.  A parameter set the library cannot take (a HUD key press can make the
     // smoothing radius zero or negative, src/hud.rs:135-138; WS_ERR_INVALID_ARG / WS_ERR_OUT_OF_MEMORY) must not take
     // the app down: the library keeps its previous parameters, and so does the worker; say so once per rejected value.
+    // (Both codes come from the checks ws_set_params makes BEFORE it touches anything.  An allocation that fails after
+    // the old cell tables were given up leaves the handle dead instead: the next ws_step reports it -- `check` below.)
     let status = unsafe { ws_set_params(h, &params) };
     if status == 0 {
         worker.params = params;

@@ -35,7 +35,9 @@ def test_rccl_transport_with_peers_direct_and_captured(ws):
         #                                                       out, every message had the size its receiver expected
         assert c["communicators"] == [2] * W, c               # ncclCommSplit: one communicator per stream
         assert c["new_communicators"] == 2 * W, c
-        assert c["sendrecv_ops"] > 100 and c["allgathers"] > 100, c  # the step really went through the transport
+        # the step really went through the transport (host-side calls into the stand-in: a captured step makes them once
+        # per capture, the replays run the recorded kernels)
+        assert c["sendrecv_ops"] > (10 if c["graph"] else 100) and c["allgathers"] > (10 if c["graph"] else 100), c
         assert c["migrated"] > 0, c
         assert all(c["mid_frame_positions_identical"]), c
         assert all(c["bit_identical_to_single_handle"]), c

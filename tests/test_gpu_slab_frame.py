@@ -196,3 +196,84 @@ def test_rebalance_moves_the_cuts_where_static_cuts_overrun(ws):
     final = [results[r][1][-1] for r in range(world)]
     assert sum(final) == pos.shape[0]
     assert max(final) - min(final) < 65536 // 3 // 2, "not balanced: %r" % (final,)
+
+
+def test_a_rank_local_overrun_with_a_collective_read_after_every_frame_fails_every_rank_at_the_same_call(ws, monkeypatch):
+    """A halo overrun is set by k_halo_pack on the rank it happens on and reaches the others only with the NEXT step's
+    all-gather.  A host that reads positions after every step (update(), src/fluid_compute.rs:478) enters the collective
+    read in between: the rank that knows must not leave it alone (its peers would wait in the all-gathers for ever) --
+    the bits travel in the read's count words and every rank refuses the view at the same call."""
+    monkeypatch.setenv("WS_LOOPBACK_TIMEOUT", "30")  # a rank left alone breaks the barrier after 30 s instead of 300
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
+    world = 3
+
+    def program(s, rank):
+        for k in range(40):
+            try:
+                s.run(1)
+            except ws.WsError as e:
+                return ("step", k, e.status, str(e))
+            try:
+                s.read_positions()
+            except ws.WsError as e:
+                return ("read", k, e.status, str(e))
+        return None
+
+    res = ws.slab.run_loopback_program(pos, params, world, program, ghost_capacity=64)  # a boundary layer holds ~1000
+    assert all(r is not None for r in res), res
+    assert len({(r[0], r[1]) for r in res}) == 1, "every rank must fail at the same call: %r" % (res,)
+    assert res[0][0] == "read", res          # the read right behind the step that overran, not a step later
+    for r in res:
+        assert r[2] == 3 and "halo" in r[3], r  # WS_ERR_OUT_OF_MEMORY, the halo message
+
+
+def test_a_regrid_that_would_overrun_a_slab_is_refused_by_every_rank_before_anything_changes(ws):
+    """h = 0.25 -> 1.0 on three slabs of a uniform cloud: equal-LAYER cuts of the coarse grid (20 layers, 16 of them
+    inside the container) would give the middle slab 7 / 16 of the fluid, more than its capacity of 0.40 n.  Every rank
+    knows every rank's new share (the gathered state) and capacity (the count words): all refuse alike, nothing has been
+    touched, the run goes on bit-identically.  After a re-cut by particle count the same re-grid is accepted -- the
+    equal-count rule is re-applied on the new grid -- and still reproduces the single handle; the migration counters
+    are cumulative over all of it."""
+    size = (16.0, 9.0, 9.0)
+    params = ws.make_params(container_size=size, gravity=(2.0, -9.8, 0.0, 0.0))
+    coarse = ws.make_params(container_size=size, gravity=(2.0, -9.8, 0.0, 0.0), smoothing_radius=1.0)
+    pos = ws.workloads.uniform_cloud(32768, 4321, list(params.ext_min), list(params.ext_max))
+    world, cap = 3, int(0.40 * 32768)
+    w = ws.FluidWorker(pos, params)
+    w.run(12)
+    want_a = w.read_vec("particles")
+    w.set_params(coarse)
+    w.run(6)
+    want_b = w.read_vec("particles")
+    w.close()
+
+    def program(s, rank):
+        s.run(6)
+        refused = None
+        try:
+            s.set_params(coarse)
+        except ws.WsError as e:
+            refused = (e.status, str(e))
+        s.run(6)                                  # ... with the old radius: the handle is untouched
+        a = s.read_vec("particles")
+        before = s.counters()
+        s.rebalance()
+        s.set_params(coarse)                      # accepted now: equal counts on the new grid
+        owned = s.num_owned()
+        after = s.counters()
+        s.run(6)
+        return refused, a, s.read_vec("particles"), owned, before, after
+
+    res = ws.slab.run_loopback_program(pos, params, world, program, capacity=cap)
+    for r, (refused, a, b, owned, before, after) in enumerate(res):
+        assert refused is not None and refused[0] == 3 and "would own" in refused[1] and "nothing was changed" in refused[1], refused
+        assert owned <= cap
+        assert after["left"] >= before["left"] and after["arrived"] >= before["arrived"]  # carried over the loads
+        for f in want_a.dtype.names:
+            assert np.array_equal(a[f].view(np.uint32), want_a[f].view(np.uint32)), (f, r)
+        for f in ("position", "velocity", "predicted_position"):
+            assert np.array_equal(b[f].view(np.uint32), want_b[f].view(np.uint32)), (f, r)
+    assert len({res[r][0] for r in range(world)}) == 1  # the same refusal everywhere
+    assert sum(res[r][3] for r in range(world)) == pos.shape[0]
+    assert sum(res[r][5]["left"] for r in range(world)) > 0

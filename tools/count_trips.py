@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer (needs a library built with -DWS_EXP_COUNT, e.g. tools/ab_build.sh count "-DWS_EXP_COUNT" and
+"""Developer (needs a library with the trip-count instrumentation patched in: tools/ab_build.sh count "" count_trips and
 WSFLUID_LIBRARY=tools/ab/libcount.so): how many trips of four candidates a K4 wave executes and with how many lanes,
 how many list entries its phase 2 walks, and the same for K5's iterator loop -- per wave, C3 cloud, sparse and settled."""
 import sys, os, ctypes as C

@@ -51,7 +51,6 @@ ws_status fail(ws_handle *h, ws_status st, const char *what, hipError_t e = hipS
             return fail(h, e_ == hipErrorOutOfMemory ? WS_ERR_OUT_OF_MEMORY : WS_ERR_HIP, #expr, e_); \
     } while (0)
 
-// Rust f32::powi -> llvm.powi -> compiler-rt __powisf2 (square-and-multiply).
 // A host <-> device copy on the HANDLE'S OWN stream, complete on return.  Never the legacy (null) stream: it
 // synchronises implicitly with streams that are none of this handle's business, and it fails outright
 // (hipErrorStreamCaptureImplicit) while any other thread of the host is capturing a hipGraph -- another handle with
@@ -62,6 +61,7 @@ hipError_t copy_now(ws_handle *h, void *dst, const void *src, size_t bytes, hipM
     return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
 }
 
+// Rust f32::powi -> llvm.powi -> compiler-rt __powisf2 (square-and-multiply).
 float powi_f32(float a, int b)
 {
     float r = 1.0f;
@@ -782,6 +782,7 @@ ws_status ws_step(ws_handle *h)
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_step(h);
     WS_REF_DISPATCH(h, ref_step(h));
+    if (h->dead) return fail(h, WS_ERR_HIP, h->err.c_str());
     hipStream_t s = h->stream;
     bound_pending(h);
     // WS_FLAG_GRAPH: the five launches as one captured graph (the reference replays its pass graph the same way,
@@ -904,8 +905,13 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->dev = nd;
     st = alloc_grid(h);
-    if (st) return st;
-    return bin_current(h);
+    if (!st) st = bin_current(h);
+    if (st) {
+        // the old cell tables are gone and the new ones are not there: no ws_step may launch on this handle again
+        h->dead = true;
+        h->err = "re-grid failed after the old cell tables were given up (" + h->err + "); the handle is unusable";
+    }
+    return st;
 }
 
 ws_status ws_read_positions(ws_handle *h, float *out_xyz)

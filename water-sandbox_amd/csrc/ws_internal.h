@@ -220,6 +220,7 @@ struct ws_handle {
     bool pred_stale = false;  // cur.pred is behind cur.pos / cur.vel (the step loop does not store it: k_reorder)
     struct WsSlab *slab = nullptr;
     bool own_stream = true;
+    bool dead = false;  // a re-grid failed after the old tables were given up: every later ws_step refuses (err says why)
 
     std::string err;
 };
@@ -263,6 +264,9 @@ struct WsSlab {
     size_t g_send_bytes = 0, g_all_bytes = 0, g_out_bytes = 0;
     std::vector<uint32_t *> retired;  // outgrown gather buffers (freed with the handle: ws_slab.inc slab_grow)
     std::vector<uint32_t> counts;     // owned particles per rank as of the last gather
+    std::vector<uint32_t> caps;       // ... and every rank's owned capacity (a re-grid decides for all ranks alike)
+    uint64_t left_base = 0, arrived_base = 0, far_base = 0;  // cumulative counters carried over the loads (ws_slab_counters)
+    bool balanced = false;            // the cuts come from ws_slab_rebalance (a re-grid re-balances on the new grid)
     uint32_t failed = 0;              // sticky WS_DYN_ERR_* bits seen on any rank
     bool comm_failed = false;         // a transport call failed: the handle is dead
     // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute

@@ -707,9 +707,6 @@ __device__ __forceinline__ void density_store(float density, float near_density,
 {
     density = density + 0.00001f;  // DENSITY_PADDING, simulation.wgsl:4,187-188
     near_density = near_density + 0.00001f;
-#ifdef ND_ABLATE_DENSITY_STORE  // ablation (wrong results): what do the two 4-byte patches cost?  one store per 64 particles instead
-    if ((i & 63u) != 0u) return;
-#endif
     srt.pred(i).w = density;
     srt.vel(i).w = near_density;
 }
@@ -941,17 +938,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 // share one), each with its own L2: tile = f(b) gives every XCD one CONTIGUOUS eighth of the sorted order (an
 // x-slab of the domain), so a tile's neighbour records are fetched into one L2 instead of into all eight.
 // Speed / traffic only: any placement computes the same thing.
-#ifndef WS_XCD_TILES
-#define WS_XCD_TILES 1
-#endif
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nt)
 {
-#if WS_XCD_TILES
     const uint32_t xcd = b & 7u, q = nt >> 3, r = nt & 7u;
     return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
-#else
-    return b;
-#endif
 }
 
 typedef float nd_f4 __attribute__((ext_vector_type(4)));
@@ -972,10 +962,6 @@ __device__ __forceinline__ void run_bounds(const uint32_t *__restrict__ start, i
 // squared distances as packed f32 vector arithmetic (same IEEE operations per candidate, same order).
 // Lanes past their run's end keep loading in-bounds slots (the planes are padded) and are masked
 // out of the accept test.  note(nvalid, bits): the trip tested nvalid candidates, bit u = candidate u accepted.
-#ifdef WS_EXP_COUNT
-__device__ uint32_t g_exp[8];
-extern "C" void ws_exp_read(uint32_t *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exp), sizeof(uint32_t) * 8); uint32_t z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_exp), z, sizeof z); }
-#endif
 template <class Push, class Phase2, class Note>
 __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t j, uint32_t e, uint32_t &cnt,
                                               WsXYZ p, Push &&push, Phase2 &&phase2, Note &&note)
@@ -987,16 +973,9 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
     bool more = rem > 0;
     auto trip = [&]() {
         const nd_f4 X = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.x) + off);
-#ifdef ND_ABLATE_PLANES  // ablation (wrong results): one candidate load per trip instead of three -- is phase 1 bound by its loads?
-        const nd_f4 Y = X, Z = X;
-#else
         const nd_f4 Y = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.y) + off);
         const nd_f4 Z = *reinterpret_cast<const nd_f4u *>(reinterpret_cast<const char *>(p.z) + off);
-#endif
         __builtin_amdgcn_sched_barrier(0);  // the three loads are issued before any is consumed
-#ifdef WS_EXP_COUNT
-        { const unsigned long long act = __ballot(true); if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) { atomicAdd(&g_exp[1], 1u); atomicAdd(&g_exp[3], (uint32_t)__popcll(act)); } }
-#endif
         const nd_f4 ex = X - o.x, ey = Y - o.y, ez = Z - o.z;
         const nd_f4 d2 = ex * ex + ey * ey + ez * ez;
         uint32_t bits = 0;
@@ -1045,9 +1024,6 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     const bool valid = v < sp.len;
     const uint32_t iv = span_at(sp, valid ? v : sp.len - 1u), i = iv;  // lanes past the end shadow the last particle
     const float4 o = make_float4(sxyz.x[iv], sxyz.y[iv], sxyz.z[iv], 0.f);  // the planar copy: coalesced, same bits
-#ifdef ND_FULL_STORE
-    const float4 own_vel = srt.vel(iv);
-#endif
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
     float density = 0.f, near_density = 0.f;
@@ -1059,9 +1035,6 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     uint32_t *mrow = mask.words + (iv - d.base);
     auto push = [&](uint32_t slot, float d2) { list[slot * ND_P + threadIdx.x] = d2; };
     auto phase2 = [&](uint32_t cnt) {
-#ifdef WS_EXP_COUNT
-        { uint32_t m = cnt; for (int sh = 32; sh >= 1; sh >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sh, 64)); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_exp[2], m); atomicAdd(&g_exp[4], 1u); } }
-#endif
         uint32_t k = 0;
         for (; k + 2u <= cnt; k += 2u) {  // two list entries per pass: their LDS reads and square roots overlap
             const float a = list[k * ND_P + threadIdx.x], b = list[(k + 1u) * ND_P + threadIdx.x];
@@ -1074,9 +1047,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         acc32 |= bits << pos;
         pos += nvalid;
         if (pos >= 32u) {  // pos was >= 28, so the shift below is by 1..4
-#ifndef ND_ABLATE_MASK_STORE  // ablation (wrong results): what do the accept-mask stores cost?
             if (word < ND_MASK_WORDS) mrow[(size_t)word * mask.stride] = acc32;
-#endif
             pos -= 32u;
             acc32 = bits >> (nvalid - pos);  // the bits that spilled over: the trip's last `pos` ones
             word++;
@@ -1093,9 +1064,6 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         cut_run_t<CUT>(d, b0, e0);
         cut_run_t<CUT>(d, b1, e1);
         cut_run_t<CUT>(d, b2, e2);
-#ifdef ND_ABLATE_EMPTY  // ablation (wrong results): every run empty -- what is K4 without its candidates?
-        e0 = b0; e1 = b1; e2 = b2;
-#endif
         if (!valid) {
             e0 = b0;
             e1 = b1;
@@ -1109,13 +1077,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     if (valid) {
         if (pos && word < ND_MASK_WORDS) mrow[(size_t)word * mask.stride] = acc32;
         if (32u * word + pos > 32u * ND_MASK_WORDS) atomicAdd(&stats[0], 1u);  // rare by construction: one counter is enough
-#ifdef ND_FULL_STORE
-        // experiment: the whole 32-byte record rewritten (two 16-byte stores: full sectors) instead of two 4-byte patches
-        srt.pred(i) = make_float4(o.x, o.y, o.z, density + 0.00001f);
-        srt.vel(i) = make_float4(own_vel.x, own_vel.y, own_vel.z, near_density + 0.00001f);
-#else
         density_store(density, near_density, i, srt);
-#endif
     }
 }
 
@@ -1237,12 +1199,6 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         // run.  The two rare steps -- next mask word, next run -- are short and independent, so a wave in which some
         // lane takes one of them on almost every trip (9 words and 9 runs per lane in the dense state) pays ~15
         // instructions for it, not the ~40 of a combined word-and-run segment computation.
-#ifdef NF_PREFETCH_RUN
-        // The next run's table entries are fetched from LDS when the current run is entered, so that a run switch is
-        // two register moves and never waits for LDS (some lane of a dense wave switches runs on nearly every trip,
-        // and the whole wave would wait for its LDS round trip).
-        uint32_t end_n = t_end[NF_P + threadIdx.x], delta_n = t_delta[NF_P + threadIdx.x];
-#endif
         auto next = [&](uint32_t &j) -> bool {
             while (rest == 0u) {
                 if (widx >= nwords) return false;
@@ -1254,21 +1210,11 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
             }
             const uint32_t sc = wbase + (uint32_t)__ffs((int)rest) - 1u;
             rest &= rest - 1u;
-#ifdef NF_PREFETCH_RUN
-            while (sc >= end_r) {
-                run++;
-                end_r = end_n;
-                delta_r = delta_n;
-                end_n = t_end[min(run + 1u, 9u) * NF_P + threadIdx.x];
-                delta_n = t_delta[min(run + 1u, 8u) * NF_P + threadIdx.x];
-            }
-#else
             while (sc >= end_r) {
                 run++;
                 end_r = t_end[run * NF_P + threadIdx.x];
                 delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
             }
-#endif
             j = sc + delta_r;
             return true;
         };
@@ -1279,9 +1225,6 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         float4 q_next = srt.pred_near(j1), nvel_next = srt.vel_near(j1);
         bool have1 = have0 && next(j2);
         while (have0) {
-#ifdef WS_EXP_COUNT
-            { const unsigned long long act = __ballot(true); if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)act) - 1)) { atomicAdd(&g_exp[5], 1u); atomicAdd(&g_exp[6], (uint32_t)__popcll(act)); } }
-#endif
             const float4 q = q_next, nvel = nvel_next;
             q_next = srt.pred_near(j2);
             nvel_next = srt.vel_near(j2);

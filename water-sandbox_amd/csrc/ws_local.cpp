@@ -50,6 +50,14 @@ struct LocalHub {
         }
         return !broken;
     }
+    // a rank that cannot go on (a HIP error of its own) breaks the hub for everybody at once: its peers fail at their
+    // next barrier instead of waiting out the time limit for a rank that will never arrive
+    void fail_all()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
+    }
 };
 
 struct LocalTransport {
@@ -63,7 +71,10 @@ int local_sendrecv(void *ctx, uint32_t nseg, void *const send_ptr[], const uint6
     LocalTransport *t = static_cast<LocalTransport *>(ctx);
     LocalHub *hub = t->hub;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipStreamSynchronize(s) != hipSuccess) return 1;  // my boundary data is final before anybody reads it
+    if (hipStreamSynchronize(s) != hipSuccess) {  // my boundary data is final before anybody reads it
+        hub->fail_all();
+        return 1;
+    }
     hub->offer[t->rank].send_ptr = send_ptr;
     hub->offer[t->rank].send_bytes = send_bytes;
     hub->offer[t->rank].nseg = nseg;
@@ -74,8 +85,12 @@ int local_sendrecv(void *ctx, uint32_t nseg, void *const send_ptr[], const uint6
         const uint32_t d = i % 2;  // my left neighbour's right-going segment is entry i + 1 of its lists, and vice versa
         const uint32_t peer = d == 0 ? t->rank - 1 : t->rank + 1;
         const uint32_t j = d == 0 ? i + 1 : i - 1;
+        if (peer >= hub->world) {  // (rank 0's left peer is UINT32_MAX: checked BEFORE the offer table is indexed)
+            rc = 3;
+            break;
+        }
         const LocalHub::Offer &o = hub->offer[peer];
-        if (peer >= hub->world || o.nseg != nseg || o.send_bytes[j] != recv_bytes[i]) {
+        if (o.nseg != nseg || o.send_bytes[j] != recv_bytes[i]) {
             rc = 3;  // the two ends disagree about a message size
             break;
         }
@@ -91,7 +106,10 @@ int local_allgather(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t by
     LocalTransport *t = static_cast<LocalTransport *>(ctx);
     LocalHub *hub = t->hub;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        hub->fail_all();
+        return 1;
+    }
     hub->offer[t->rank].gather_ptr = send_ptr;
     if (!hub->barrier()) return 2;
     int rc = 0;
