@@ -52,7 +52,7 @@ HBM_COPY_GBS = 6290.0  # achievable: float4 copy measured on MI355X (MI355X_MICR
 C3_PARTICLES = 4194304
 SETTLED_FROM = 400     # first step of the settled window
 SETTLED_STEPS = 100
-PROFILES_ROUND = "r03"
+PROFILES_ROUND = "r04"
 PROFILES = os.path.join(ROOT, "profiles", PROFILES_ROUND)
 # VALU issue peak of the chip: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (a packed-f32 or
 # transcendental instruction takes more: the fraction below is a lower bound of how busy the VALU issue ports are)
@@ -151,7 +151,8 @@ def load_traffic(config, dist, warmup, steps, kernel):
         v = t.get(key, {}).get("bytes_per_launch", {}).get(kernel)
         if v is None:
             return None, None
-        return v, "profiles/%s/traffic.json[%s]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this window" % (PROFILES_ROUND, key)
+        return v, ("profiles/%s/traffic.json[%s]: separate rocprofv3 --pmc passes of this window, size-resolved read requests "
+                   "(TCC_EA0_RDREQ_32B / _64B / _128B) + WRITE_SIZE" % (PROFILES_ROUND, key))
     except (OSError, ValueError):
         return None, None
 
@@ -171,23 +172,24 @@ def load_window_counters(config, dist, warmup, steps):
 
 
 def step_traffic(counters, ms_per_step):
-    """Counter-measured HBM bytes of ALL five kernels of a step (2 x FETCH_SIZE + WRITE_SIZE each, the gfx950 half-count
-    correction of MI355X_MICROARCH.md applied to every kernel) over the step time, against the measured float4-copy
-    rate: the measured-bytes view of the WHOLE step."""
+    """Counter-measured HBM bytes of ALL five kernels of a step over the step time, against the measured float4-copy rate:
+    the measured-bytes view of the WHOLE step.  Reads from the size-resolved fabric request counters
+    (32 n32 + 64 n64 + 128 n128 = 2 x FETCH_SIZE: every request is a 128-byte line, profiles/r04/traffic_calibration.json),
+    writes from WRITE_SIZE.  LINES moved, not useful bytes: a scattered 16-byte gather costs a line."""
     t = counters.get("traffic.json")
-    if not t:
+    if not t or "read_resolved" not in t:
         return None
     per = {}
     for label, kname in STEP_KERNELS.items():
-        f, w = _by_kernel(t["fetch_raw"], kname), _by_kernel(t["write_raw"], kname)
+        f, w = _by_kernel(t["read_resolved"], kname), _by_kernel(t["write_raw"], kname)
         if f is None or w is None:
             return None
-        per[label] = 2.0 * f + w
+        per[label] = f + w
     total = sum(per.values())
     gbps = total / (ms_per_step * 1e-3) / 1e9
     return {"bytes_per_step": total, "bytes_per_kernel": per, "GBps": gbps, "frac_of_measured_copy_bw": gbps / HBM_COPY_GBS,
-            "source": "profiles/%s/traffic.json (2 x FETCH_SIZE + WRITE_SIZE of the five step kernels) / this run's ms_per_step"
-                      % PROFILES_ROUND}
+            "source": "profiles/%s/traffic.json (size-resolved read requests + WRITE_SIZE of the five step kernels) / this "
+                      "run's ms_per_step" % PROFILES_ROUND}
 
 
 def secondary_roofline(counters, label, avg_s):
