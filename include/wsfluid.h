@@ -370,7 +370,9 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * sweep in the force kernel); out[1..3] = how many of the reference's cells (edge = smoothing radius) one cell of the
  * device grid spans along x, y, z -- 1 unless the reference-sized grid would exceed the cell budget (a small
  * smoothing radius in a big container), see ws_grid_dims; out[4] = steps replayed from a captured hipGraph
- * (WS_FLAG_GRAPH); the rest reserved. */
+ * (WS_FLAG_GRAPH); slab handles: out[5] = the most particles one of this slab's boundary layers has held since the last
+ * load and out[6] = the halo capacity it must stay under (ws_device_cfg.ghost_capacity), out[7] = the most particles
+ * that left towards one neighbour in one step and out[8] = the migration message's capacity; the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

@@ -896,7 +896,12 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
     h->params = *params;
     if (!regrid) {
         // (update() pushes the same parameters every frame, src/fluid_compute.rs:479-481: a captured step survives that)
-        if (memcmp(&h->dev, &nd, sizeof nd) != 0) drop_graphs(h);
+        if (memcmp(&h->dev, &nd, sizeof nd) != 0) {
+            drop_graphs(h);
+            // new dynamics (a gravity flip can set the whole fluid in motion within a few steps): a slab's messages
+            // travel at full capacity until the counts of the new regime have come round (every rank makes this call)
+            if (h->slab) h->slab->limit_hold = 8;
+        }
         h->dev = nd;  // by-value kernel argument: picked up by the next ws_step
         return WS_OK;
     }
@@ -1209,6 +1214,14 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
     HIP_TRY(h, copy_now(h, out, h->stats, 64, hipMemcpyDeviceToHost));
     for (int c = 0; c < 3; c++) out[1 + c] = (uint32_t)h->dev.cm[c];  // reference cells merged per grid cell (host-side)
     out[4] = (uint32_t)(h->slab ? h->slab->graph_steps : h->graph_steps);  // steps replayed from a captured graph
+    if (h->slab) {  // how close the fixed message capacities came to overrunning, since the last load
+        uint32_t dyn[WS_DYN_WORDS];
+        HIP_TRY(h, copy_now(h, dyn, h->slab->dyn, sizeof dyn, hipMemcpyDeviceToHost));
+        out[5] = dyn[DY_PEAK_HALO];
+        out[6] = h->slab->halo_cap;
+        out[7] = dyn[DY_PEAK_MIG];
+        out[8] = h->slab->mig_cap;
+    }
     return WS_OK;
 }
 

@@ -59,6 +59,7 @@ struct WsDev {
     uint32_t has_left, has_right;  // x-neighbours present
     uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
     const WsMig *mig;              // device copy; non-null = the force epilogue also does migration part 1
+    uint32_t mig_limit;            // records the NEXT step's migration messages will carry (<= WsMig::mig_cap; 0 = all of it)
 };
 
 // words of the device block `dyn` of a slab handle
@@ -74,6 +75,9 @@ enum {
     DY_STEP,         // steps whose migration has run since the handle was created / reset (k_migrate_fill counts): the
                      // stamp of every message and the slot of the status ring come from here, not from the host, so a
                      // captured graph of the step replays unchanged
+    DY_HALO_NOW,     // the larger of this step's two boundary-layer populations (k_halo_pack; k_migrate_fill hands it on and clears it)
+    DY_PEAK_HALO,    // since the last load: the most particles a boundary layer of this slab held (records of a halo message)
+    DY_PEAK_MIG,     // ... and the most particles that left towards ONE neighbour in one step (records of a migration message)
     WS_DYN_WORDS = 16
 };
 enum {
@@ -84,7 +88,8 @@ enum {
     WS_DYN_ERR_STAMP = 16u      // a message stamped with another step arrived: the transport delivered out of order
 };
 enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LATE_RIGHT = 3, WS_RANGE_LATE_BOTH = 4 };
-#define WS_HDR_WORDS_HOST 4u  // words of a message header (ws_kernels.hip WS_HDR_WORDS)
+#define WS_HDR_WORDS_HOST 8u  // words of a message header (ws_kernels.hip WS_HDR_WORDS)
+#define WS_HDR_UNKNOWN 0xFFFFFFFFu  // header words 4 / 5 before the first migration / halo of a particle set has been counted
 
 // density / force kernel family (WS_VARIANT=simple in the environment, for A/B tests)
 enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_LISTED = 2 };
@@ -226,7 +231,7 @@ struct ws_handle {
 };
 
 struct WsGraphEntry {
-    uint32_t n_bound = 0;
+    uint32_t n_bound = 0, mig_cur = 0, mig_next = 0, halo = 0;  // what a captured step has baked in
     hipGraphExec_t exec = nullptr;
 };
 struct WsSlab {
@@ -240,6 +245,16 @@ struct WsSlab {
     uint32_t far_cap = 0;    // records of the all-gathered message for particles that cross several slabs
     uint32_t hole_cap = 0;   // leavers per step (all routes)
     uint32_t max_arrivals = 0;
+    // Message SIZES follow the fluid (round 4).  The buffers keep their fixed capacities; what travels each step is a
+    // prefix sized from what every rank reported three to four steps ago (header words 4 / 5 of the all-gathered far
+    // message = the status table): the same table on every rank, hence the same size at both ends of every exchange.
+    uint32_t mig_limit_cur = 0;       // records of the migration messages exchanged by the step being enqueued
+    uint32_t mig_limit_next = 0;      // ... by the next one (the force kernel of this step fills them: WsDev::mig_limit)
+    uint32_t halo_limit = 0, halo_limit_next = 0;  // records of this step's / the next step's halo messages
+    uint32_t want_mig = 0, want_halo = 0;   // the newest table's maxima over all ranks (header words 4 / 5)
+    uint64_t arrivals_hist[4] = {0, 0, 0, 0};  // upper bounds of the arrivals of the last four steps (launch bound)
+    uint32_t limit_hold = 0;          // steps for which the limits stay at the full capacities (after a load / parameter change)
+    bool fixed_messages = false;      // WS_SLAB_FIXED_MESSAGES=1: always the full capacities (rounds 1-3)
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
     uint32_t *cuts_dev = nullptr;
     uint32_t *dyn = nullptr;          // WS_DYN_WORDS device words (DY_*)

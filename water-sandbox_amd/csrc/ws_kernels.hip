@@ -713,10 +713,13 @@ __device__ __forceinline__ void density_store(float density, float near_density,
 
 // ---- slab handles: migration, part 1 -------------------------------------------------------------------------
 
-// message header: 4 words in front of every fixed-capacity message
+// message header: 8 words in front of every fixed-capacity message
 //   [0] records in the message   [1] sender's sticky error bits   [2] sender's owned count   [3] step stamp
-// ([1..3] matter in the all-gathered far message only: its headers are the per-step status table of all ranks)
-#define WS_HDR_WORDS 4u
+//   [4] the most records either of the sender's two migration messages of the previous exchange wanted to carry
+//   [5] the larger of the sender's two boundary-layer populations at the previous step's halo   [6..7] reserved
+// ([1..5] matter in the all-gathered far message only: its headers are the per-step status table of all ranks; from
+// [4] / [5] every rank sizes the next steps' messages -- the same table everywhere, hence the same sizes)
+#define WS_HDR_WORDS 8u
 
 // The particle in slot i (not in the histogram, its cell id already WS_DEAD) left the slab: write its 64-byte record
 // {pos+id, vel, pred, destination} into the message for its route -- left neighbour, right neighbour, or the small
@@ -733,10 +736,11 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
     if (hs < m.hole_cap) m.hole[hs] = i;
     uint32_t *msg;
     uint32_t cap;
+    const uint32_t mig_cap = d.mig_limit ? min(d.mig_limit, m.mig_cap) : m.mig_cap;  // what the next exchange will carry
     if (dest + 1u == m.me) {
-        msg = m.sendL; cap = m.mig_cap;
+        msg = m.sendL; cap = mig_cap;
     } else if (dest == m.me + 1u) {
-        msg = m.sendR; cap = m.mig_cap;
+        msg = m.sendR; cap = mig_cap;
     } else {
         msg = m.far; cap = m.far_cap;
         atomicAdd(&m.dyn[DY_FAR], 1u);
@@ -1623,6 +1627,8 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         dyn[DY_NHOLE] = 0;
         dyn[DY_ARRIVED] += s_arr;
         dyn[DY_LEFT] += leave;
+        const uint32_t wanted = max(sendL[0], sendR[0]);  // (the counts of the messages just exchanged, clamped or not)
+        dyn[DY_PEAK_MIG] = max(dyn[DY_PEAK_MIG], wanted);
         // the three outgoing migration messages of the NEXT step: counts back to zero (migrate_out counts in
         // place), and the status words every rank will read from the far message's header: sticky error bits, the
         // owned count and the step they describe
@@ -1634,6 +1640,9 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         far_send[1] = dyn[DY_ERR];
         far_send[2] = n_new;
         far_send[3] = step + 1u;
+        far_send[4] = wanted;
+        far_send[5] = dyn[DY_HALO_NOW];  // the previous step's halo (this step's has not been packed yet)
+        dyn[DY_HALO_NOW] = 0;
     }
 }
 
@@ -1670,6 +1679,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_pack(WsDev d, const uint32_t 
     }
     if (t == 0) {
         if (cnt_all > halo_cap) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_HALO);
+        atomicMax(&dyn[DY_PEAK_HALO], cnt_all);
+        atomicMax(&dyn[DY_HALO_NOW], cnt_all);
         msg[0] = cnt;
         msg[1] = dyn[DY_ERR];
         msg[2] = dyn[DY_N];

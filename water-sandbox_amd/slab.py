@@ -378,7 +378,10 @@ class SlabWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        return {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4])}
+        st = {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4])}
+        if out[6]:  # a slab handle: peaks of the fixed-capacity messages against their capacities
+            st.update(halo_peak=int(out[5]), halo_capacity=int(out[6]), migration_peak=int(out[7]), migration_capacity=int(out[8]))
+        return st
 
     def rebalance(self):
         """ws_slab_rebalance (collective): re-cut the slabs to equal particle counts."""
