@@ -372,7 +372,8 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * smoothing radius in a big container), see ws_grid_dims; out[4] = steps replayed from a captured hipGraph
  * (WS_FLAG_GRAPH); slab handles: out[5] = the most particles one of this slab's boundary layers has held since the last
  * load and out[6] = the halo capacity it must stay under (ws_device_cfg.ghost_capacity), out[7] = the most particles
- * that left towards one neighbour in one step and out[8] = the migration message's capacity; the rest reserved. */
+ * that left towards one neighbour in one step and out[8] = the migration message's capacity, out[9] = the most that crossed
+ * more than one slab in one step and out[10] = the far message's capacity; the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

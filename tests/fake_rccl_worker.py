@@ -93,6 +93,11 @@ def main():
         return rec, mid, w.stats(), w.counters(), own, again, int(fake.fake_rccl_errors())  # (while the communicators live)
 
     for world, graph in ((2, False), (3, False), (4, False), (2, True), (4, True)):
+        # Captured cases with messages of FIXED size: a change of the message sizes asks for a new capture, and
+        # hipGraphInstantiate / hipGraphExecDestroy in the middle of a run wait for the whole device -- including the
+        # transport kernels of the other ranks of THIS process, which are waiting for this rank (real ranks are
+        # processes).  The direct cases run with the default: sizes that follow the fluid.
+        os.environ["WS_SLAB_FIXED_MESSAGES"] = "1" if graph else "0"
         before = calls()
         res = run_world(pos, params, world, program, graph)
         after = calls()

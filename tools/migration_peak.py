@@ -23,18 +23,26 @@ nx = int(size[0] / 0.25) + 4
 
 
 def program(s, rank):
-    out, last = [], 0
+    out, last, st = [], 0, None
+    every = int(os.environ.get("MIG_EVERY", "5"))
     for k in range(steps):
-        s.run(1)
-        if k % 5 == 4 or k > steps - 3:
-            c = s.counters()
-            out.append((k, c["left"] - last, c["owned"], c["far"]))
-            last = c["left"]
-    return out, s.stats()
+        try:
+            s.run(1)
+            if k % every == every - 1 or k > steps - 3:
+                c = s.counters()
+                st = s.stats()
+                out.append((k, c["left"] - last, c["owned"], c["far"]))
+                last = c["left"]
+        except ws.WsError as e:
+            return out, st, "step %d: %s" % (k, e)
+    return out, s.stats(), None
 
 
 res = ws.slab.run_loopback_program(pos, params, world, program, capacity=int(n / world * 1.6))  # default message capacities
-for r, (rows, st) in enumerate(res):
+for r, (rows, st, failed) in enumerate(res):
+    if failed:
+        print(json.dumps({"rank": r, "FAILED": failed, "last_stats": st, "rows": rows[-4:]}), flush=True)
+        continue
     peak = max(rows, key=lambda x: x[1])
     print(json.dumps({"config": "%sx%d" % (cfg, copies), "world": world, "rank": r, "particles": n,
                       "peak_leavers_per_5_steps": peak[1], "at_step": peak[0], "owned_min_max": [min(x[2] for x in rows), max(x[2] for x in rows)],

@@ -1221,6 +1221,8 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
         out[6] = h->slab->halo_cap;
         out[7] = dyn[DY_PEAK_MIG];
         out[8] = h->slab->mig_cap;
+        out[9] = dyn[DY_PEAK_FAR];
+        out[10] = h->slab->far_cap;
     }
     return WS_OK;
 }

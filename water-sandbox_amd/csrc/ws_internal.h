@@ -60,6 +60,7 @@ struct WsDev {
     uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
     const WsMig *mig;              // device copy; non-null = the force epilogue also does migration part 1
     uint32_t mig_limit;            // records the NEXT step's migration messages will carry (<= WsMig::mig_cap; 0 = all of it)
+    uint32_t far_limit;            // ... and its all-gathered far message (<= WsMig::far_cap; 0 = all of it)
 };
 
 // words of the device block `dyn` of a slab handle
@@ -78,6 +79,7 @@ enum {
     DY_HALO_NOW,     // the larger of this step's two boundary-layer populations (k_halo_pack; k_migrate_fill hands it on and clears it)
     DY_PEAK_HALO,    // since the last load: the most particles a boundary layer of this slab held (records of a halo message)
     DY_PEAK_MIG,     // ... and the most particles that left towards ONE neighbour in one step (records of a migration message)
+    DY_PEAK_FAR,     // ... and the most that crossed more than one slab in one step (records of the far message)
     WS_DYN_WORDS = 16
 };
 enum {
@@ -231,7 +233,7 @@ struct ws_handle {
 };
 
 struct WsGraphEntry {
-    uint32_t n_bound = 0, mig_cur = 0, mig_next = 0, halo = 0;  // what a captured step has baked in
+    uint32_t n_bound = 0, mig_cur = 0, mig_next = 0, halo = 0, far_cur = 0, far_next = 0;  // what a captured step has baked in
     hipGraphExec_t exec = nullptr;
 };
 struct WsSlab {
@@ -250,6 +252,7 @@ struct WsSlab {
     // message = the status table): the same table on every rank, hence the same size at both ends of every exchange.
     uint32_t mig_limit_cur = 0;       // records of the migration messages exchanged by the step being enqueued
     uint32_t mig_limit_next = 0;      // ... by the next one (the force kernel of this step fills them: WsDev::mig_limit)
+    uint32_t far_limit_cur = 0, far_limit_next = 0, want_far = 0;  // the same for the all-gathered far message
     uint32_t halo_limit = 0, halo_limit_next = 0;  // records of this step's / the next step's halo messages
     uint32_t want_mig = 0, want_halo = 0;   // the newest table's maxima over all ranks (header words 4 / 5)
     uint64_t arrivals_hist[4] = {0, 0, 0, 0};  // upper bounds of the arrivals of the last four steps (launch bound)

@@ -742,7 +742,7 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
     } else if (dest == m.me + 1u) {
         msg = m.sendR; cap = mig_cap;
     } else {
-        msg = m.far; cap = m.far_cap;
+        msg = m.far; cap = d.far_limit ? min(d.far_limit, m.far_cap) : m.far_cap;
         atomicAdd(&m.dyn[DY_FAR], 1u);
     }
     const uint32_t slot = atomicAdd(&msg[0], 1u);
@@ -1629,6 +1629,7 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         dyn[DY_LEFT] += leave;
         const uint32_t wanted = max(sendL[0], sendR[0]);  // (the counts of the messages just exchanged, clamped or not)
         dyn[DY_PEAK_MIG] = max(dyn[DY_PEAK_MIG], wanted);
+        dyn[DY_PEAK_FAR] = max(dyn[DY_PEAK_FAR], far_all[(size_t)me * far_words]);  // (what this rank's far message wanted to carry)
         // the three outgoing migration messages of the NEXT step: counts back to zero (migrate_out counts in
         // place), and the status words every rank will read from the far message's header: sticky error bits, the
         // owned count and the step they describe
@@ -1669,6 +1670,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_halo_pack(WsDev d, const uint32_t 
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     const uint32_t side = blockIdx.y;  // 0: the left-going layer (1), 1: the right-going layer (nxl - 2)
+    // no neighbour on that side, no message: the layer at the container's wall is not a boundary layer (round 4: it was
+    // packed and COUNTED all the same -- particles pile up against the wall, and an end slab failed with "a boundary
+    // layer holds more particles than a halo message" for a message nobody sends)
+    if (side ? !d.has_right : !d.has_left) return;
     uint32_t *msg = side ? sendR : sendL;
     const uint32_t first = side ? d.lidx[2] : d.lidx[0];  // index of the layer's first cell start
     const uint32_t s0 = start[first], cnt_all = start[first + rowy] - s0;
