@@ -202,3 +202,33 @@ def test_slab_step_only_enqueues(ws):
     assert w.num_owned() == pos.shape[0]
     w.close()
     tr.close()
+
+
+@pytest.mark.parametrize("fixed", ["0", "1"])
+def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
+    """The buffers of a slab's messages have fixed capacities (sized for the violent phase of a collapsing cloud); what
+    TRAVELS per step is a prefix sized from what every rank reported a few steps ago -- the same all-gathered table on
+    every rank, hence the same size at both ends of every exchange.  WS_SLAB_FIXED_MESSAGES=1 keeps the capacities.
+    Either way the result is the single handle's, bit for bit."""
+    monkeypatch.setenv("WS_SLAB_FIXED_MESSAGES", fixed)
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
+    pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
+    steps, world = 40, 3
+    want = _single(ws, pos, params, steps)
+
+    def program(s, rank):
+        s.run(steps)
+        return s.read_vec("particles"), s.stats()
+
+    res = ws.slab.run_loopback_program(pos, params, world, program)
+    for rec, st in res:
+        for f in want.dtype.names:
+            assert np.array_equal(rec[f].view(np.uint32), want[f].view(np.uint32)), f
+        assert 0 < st["migration_peak"] <= st["migration_now"] <= st["migration_capacity"]
+        assert 0 < st["halo_peak"] <= st["halo_now"] <= st["halo_capacity"]
+        if fixed == "1":
+            assert (st["migration_now"], st["halo_now"], st["far_now"]) == (st["migration_capacity"], st["halo_capacity"], st["far_capacity"])
+        else:
+            assert st["migration_now"] < st["migration_capacity"] // 4 and st["halo_now"] < st["halo_capacity"]
+            assert st["far_now"] < st["far_capacity"] // 16
+    assert len({(st["migration_now"], st["halo_now"], st["far_now"]) for _, st in res}) == 1  # the same on every rank

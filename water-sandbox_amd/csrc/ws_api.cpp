@@ -1223,6 +1223,9 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
         out[8] = h->slab->mig_cap;
         out[9] = dyn[DY_PEAK_FAR];
         out[10] = h->slab->far_cap;
+        out[11] = h->slab->mig_limit_next;   // what the next step's messages will carry (they follow the fluid)
+        out[12] = h->slab->halo_limit_next;
+        out[13] = h->slab->far_limit_next;
     }
     return WS_OK;
 }

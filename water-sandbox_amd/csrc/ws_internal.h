@@ -80,7 +80,9 @@ enum {
     DY_PEAK_HALO,    // since the last load: the most particles a boundary layer of this slab held (records of a halo message)
     DY_PEAK_MIG,     // ... and the most particles that left towards ONE neighbour in one step (records of a migration message)
     DY_PEAK_FAR,     // ... and the most that crossed more than one slab in one step (records of the far message)
-    WS_DYN_WORDS = 16
+    // scratch of the multi-kernel migration fill (k_fill_*: a step that moves more than a few ten thousand particles)
+    DY_F_FAR, DY_F_NTGT, DY_F_NSRC, DY_F_NOLD, DY_F_NNEW, DY_F_ARR, DY_F_LEAVE, DY_F_NL, DY_F_NR, DY_F_WANTED,
+    WS_DYN_WORDS = 32
 };
 enum {
     WS_DYN_ERR_MIGRATION = 1u,  // more leavers than a migration message holds
@@ -254,7 +256,8 @@ struct WsSlab {
     uint32_t mig_limit_next = 0;      // ... by the next one (the force kernel of this step fills them: WsDev::mig_limit)
     uint32_t far_limit_cur = 0, far_limit_next = 0, want_far = 0;  // the same for the all-gathered far message
     uint32_t halo_limit = 0, halo_limit_next = 0;  // records of this step's / the next step's halo messages
-    uint32_t want_mig = 0, want_halo = 0;   // the newest table's maxima over all ranks (header words 4 / 5)
+    uint32_t want_mig = 0, want_halo = 0;   // maxima over all ranks (header words 4 / 5) and over the last eight tables
+    uint32_t want_ring[3][8] = {};          // the last eight tables' maxima: migration, halo, far
     uint64_t arrivals_hist[4] = {0, 0, 0, 0};  // upper bounds of the arrivals of the last four steps (launch bound)
     uint32_t limit_hold = 0;          // steps for which the limits stay at the full capacities (after a load / parameter change)
     bool fixed_messages = false;      // WS_SLAB_FIXED_MESSAGES=1: always the full capacities (rounds 1-3)

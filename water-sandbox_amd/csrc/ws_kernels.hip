@@ -15,6 +15,7 @@
 // hashed-bucket order).  Every parity test applies ONE tolerance to both forms.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "ws_internal.h"
@@ -1647,15 +1648,202 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
     }
 }
 
+// ---- the same in five launches, for steps that move many particles --------------------------------------------
+// k_migrate_fill is ONE workgroup: right for the few thousand migrants per step it was written for, 2 ms per step (up to
+// 9) once a collapsed cloud sloshes through four slabs with 10^5 .. 10^6 migrants per slab and step (round 4,
+// profiles/r04/slab/).  The host knows the sizes of the step's messages; above a threshold it launches this sequence
+// instead: count far arrivals -> plan (one thread) -> build the target / source lists with wave-aggregated global
+// cursors -> apply -> finish (one thread).  Any pairing of sources and targets gives the same result (the sort is
+// canonical), so the two forms are interchangeable.
+__device__ __forceinline__ uint32_t wave_append(uint32_t *__restrict__ cursor, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (!want) return 0xFFFFFFFFu;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(WS_BLOCK) k_fill_count(uint32_t world, uint32_t me, uint32_t *__restrict__ dyn,
+                                                         const uint32_t *__restrict__ recvL, const uint32_t *__restrict__ recvR,
+                                                         const uint32_t *__restrict__ far_all, uint32_t far_cap,
+                                                         uint32_t *__restrict__ status_ring, uint32_t status_slots)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    const uint32_t step = dyn[DY_STEP];  // (k_fill_finish advances it)
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+    if (t < world) {
+        uint32_t *status = status_ring + (size_t)(step % status_slots) * world * WS_HDR_WORDS;
+        const uint32_t *msg = far_all + (size_t)t * far_words;
+        for (uint32_t w = 0; w < WS_HDR_WORDS; w++) status[t * WS_HDR_WORDS + w] = msg[w];
+        if (msg[3] != step) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);
+    }
+    if (t == 0 && ((me > 0 && recvL[3] != step) || (me + 1 < world && recvR[3] != step))) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);
+    bool hit = false;
+    if (t < world * far_cap) {
+        const uint32_t q = t / far_cap, k = t % far_cap;
+        const uint32_t *msg = far_all + (size_t)q * far_words;
+        if (q != me && k < min(msg[0], far_cap))
+            hit = __float_as_uint((reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k)[3].x) == me;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&dyn[DY_F_FAR], (uint32_t)__popcll(m));
+}
+
+__global__ void k_fill_plan(uint32_t world, uint32_t me, uint32_t cap, uint32_t *__restrict__ dyn, const uint32_t *__restrict__ recvL,
+                            const uint32_t *__restrict__ recvR, uint32_t mig_cap, uint32_t hole_cap)
+{
+    const uint32_t nL = me > 0 ? min(recvL[0], mig_cap) : 0u, nR = me + 1 < world ? min(recvR[0], mig_cap) : 0u;
+    const uint32_t leave = min(dyn[DY_NHOLE], hole_cap);
+    if (dyn[DY_NHOLE] > hole_cap) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
+    const uint32_t n_old = dyn[DY_N];
+    uint32_t arrivals = nL + nR + dyn[DY_F_FAR];
+    uint32_t n_new = n_old - leave + arrivals;
+    if (n_new > cap) {  // cannot hold them: drop the excess arrivals, flag the step
+        atomicOr(&dyn[DY_ERR], WS_DYN_ERR_CAPACITY);
+        arrivals -= n_new - cap;
+        n_new = cap;
+    }
+    dyn[DY_F_NL] = nL;
+    dyn[DY_F_NR] = nR;
+    dyn[DY_F_LEAVE] = leave;
+    dyn[DY_F_NOLD] = n_old;
+    dyn[DY_F_NNEW] = n_new;
+    dyn[DY_F_ARR] = arrivals;
+    dyn[DY_F_NTGT] = 0;
+    dyn[DY_F_NSRC] = 0;
+}
+
+// one thread per item of six segments laid end to end (their host-side upper bounds are the kernel's arguments):
+// holes | new slots when growing | survivors above the new end | left arrivals | right arrivals | far records
+__global__ void __launch_bounds__(WS_BLOCK) k_fill_lists(WsDev d, uint32_t world, uint32_t me, uint32_t *__restrict__ dyn,
+                                                         const uint32_t *__restrict__ hole, const uint32_t *__restrict__ far_all,
+                                                         uint32_t far_cap, uint32_t *__restrict__ tgt, uint32_t *__restrict__ src,
+                                                         const uint32_t *__restrict__ cid_cur, uint32_t b_leave, uint32_t b_arr,
+                                                         uint32_t b_mig)
+{
+    uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    const uint32_t n_old = dyn[DY_F_NOLD], n_new = dyn[DY_F_NNEW], leave = dyn[DY_F_LEAVE], base = d.base;
+    const uint32_t grow = n_new > n_old ? n_new - n_old : 0u, tail = n_old > n_new ? n_old - n_new : 0u;
+    bool is_tgt = false, is_src = false;
+    uint32_t value = 0;
+    if (t < b_leave) {
+        if (t < leave) {
+            value = hole[t];
+            is_tgt = value < base + n_new;
+        }
+    } else if ((t -= b_leave) < b_arr) {
+        is_tgt = t < grow;
+        value = base + n_old + t;
+    } else if ((t -= b_arr) < b_leave) {
+        if (t < tail) {
+            value = base + n_new + t;
+            is_src = cid_cur[value] != WS_DEAD;
+        }
+    } else if ((t -= b_leave) < b_mig) {
+        is_src = t < dyn[DY_F_NL];
+        value = (1u << 30) | t;
+    } else if ((t -= b_mig) < b_mig) {
+        is_src = t < dyn[DY_F_NR];
+        value = (2u << 30) | t;
+    } else if ((t -= b_mig) < world * far_cap) {
+        const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+        const uint32_t q = t / far_cap, k = t % far_cap;
+        const uint32_t *msg = far_all + (size_t)q * far_words;
+        if (q != me && k < min(msg[0], far_cap))
+            is_src = __float_as_uint((reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k)[3].x) == me;
+        value = (3u << 30) | t;
+    }
+    const uint32_t at = wave_append(&dyn[DY_F_NTGT], is_tgt);
+    if (is_tgt) tgt[at] = value;
+    const uint32_t as = wave_append(&dyn[DY_F_NSRC], is_src);
+    if (is_src) src[as] = value;
+}
+
+__global__ void __launch_bounds__(WS_BLOCK) k_fill_apply(WsDev d, const uint32_t *__restrict__ dyn, const uint32_t *__restrict__ recvL,
+                                                         const uint32_t *__restrict__ recvR, const uint32_t *__restrict__ far_all,
+                                                         uint32_t far_cap, const uint32_t *__restrict__ tgt,
+                                                         const uint32_t *__restrict__ src, WsSoA cur, uint32_t *__restrict__ cid_cur,
+                                                         uint32_t *__restrict__ count)
+{
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
+    if (t >= min(dyn[DY_F_NTGT], dyn[DY_F_NSRC])) return;  // (after a capacity overrun there are more sources: the excess is dropped)
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+    const uint32_t to = tgt[t], from = src[t];
+    const uint32_t tag = from >> 30, idx = from & 0x3FFFFFFFu;
+    if (tag) {
+        const uint32_t *msg = tag == 1u ? recvL : tag == 2u ? recvR : far_all + (size_t)(idx / far_cap) * far_words;
+        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)(tag == 3u ? idx % far_cap : idx);
+        const float4 q = rec[2];
+        cur.pos[to] = rec[0];
+        cur.vel[to] = rec[1];
+        cur.pred[to] = q;
+        const uint32_t c = grid_cell(d, q.x, q.y, q.z);
+        cid_cur[to] = c;
+        cur.rank[to] = atomicAdd(&count[c], 1u);  // the next rank of its cell (k_place)
+    } else {
+        cur.pos[to] = cur.pos[idx];
+        cur.vel[to] = cur.vel[idx];
+        cur.pred[to] = cur.pred[idx];
+        cid_cur[to] = cid_cur[idx];
+        cur.rank[to] = cur.rank[idx];
+    }
+}
+
+__global__ void k_fill_finish(uint32_t me, uint32_t *__restrict__ dyn, const uint32_t *__restrict__ far_all, uint32_t far_cap,
+                              uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send)
+{
+    const uint32_t step = dyn[DY_STEP];
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+    dyn[DY_N] = dyn[DY_F_NNEW];
+    dyn[DY_STEP] = step + 1u;
+    dyn[DY_NHOLE] = 0;
+    dyn[DY_ARRIVED] += dyn[DY_F_ARR];
+    dyn[DY_LEFT] += dyn[DY_F_LEAVE];
+    dyn[DY_F_FAR] = 0;
+    const uint32_t wanted = max(sendL[0], sendR[0]);
+    dyn[DY_PEAK_MIG] = max(dyn[DY_PEAK_MIG], wanted);
+    dyn[DY_PEAK_FAR] = max(dyn[DY_PEAK_FAR], far_all[(size_t)me * far_words]);
+    sendL[0] = 0;
+    sendR[0] = 0;
+    sendL[3] = step + 1u;
+    sendR[3] = step + 1u;
+    far_send[0] = 0;
+    far_send[1] = dyn[DY_ERR];
+    far_send[2] = dyn[DY_F_NNEW];
+    far_send[3] = step + 1u;
+    far_send[4] = wanted;
+    far_send[5] = dyn[DY_HALO_NOW];
+    dyn[DY_HALO_NOW] = 0;
+}
+
 void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me, uint32_t cap, uint32_t *dyn,
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
                       uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
                       uint32_t *sendR, uint32_t *far_send)
 {
-    hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
-                       mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status_ring, status_slots, hole_cap, sendL, sendR,
-                       far_send);
+    // (mig_cap / far_cap: the records this step's messages carry -- the host's current limits, not the buffers' capacities)
+    const uint64_t volume = 2ull * mig_cap + (uint64_t)world * far_cap;
+    if (volume <= 49152ull) {
+        hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
+                           mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status_ring, status_slots, hole_cap, sendL,
+                           sendR, far_send);
+        return;
+    }
+    const uint32_t b_leave = (uint32_t)std::min<uint64_t>(hole_cap, 2ull * mig_cap + far_cap);
+    const uint32_t b_arr = (uint32_t)std::min<uint64_t>(volume, 0x3FFFFFFFull);
+    hipLaunchKernelGGL(k_fill_count, dim3(cdiv(std::max(world * far_cap, world), WS_BLOCK)), dim3(WS_BLOCK), 0, s, world, me, dyn, recvL,
+                       recvR, far_all, far_cap, status_ring, status_slots);
+    hipLaunchKernelGGL(k_fill_plan, dim3(1), dim3(1), 0, s, world, me, cap, dyn, recvL, recvR, mig_cap, hole_cap);
+    const uint64_t items = 2ull * b_leave + b_arr + 2ull * mig_cap + (uint64_t)world * far_cap;
+    hipLaunchKernelGGL(k_fill_lists, dim3((uint32_t)((items + WS_BLOCK - 1) / WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, world, me, dyn, hole,
+                       far_all, far_cap, tgt, src, cid_cur, b_leave, b_arr, mig_cap);
+    hipLaunchKernelGGL(k_fill_apply, dim3(cdiv((uint32_t)std::min<uint64_t>((uint64_t)b_leave + b_arr, 0x7FFFFFFFull), WS_BLOCK)),
+                       dim3(WS_BLOCK), 0, s, d, dyn, recvL, recvR, far_all, far_cap, tgt, src, cur, cid_cur, count);
+    hipLaunchKernelGGL(k_fill_finish, dim3(1), dim3(1), 0, s, me, dyn, far_all, far_cap, sendL, sendR, far_send);
 }
 
 // Halo messages.  A: [header | cell-start slice of the boundary layer (rowy + 1 words, padded to 4) | its 32-byte
