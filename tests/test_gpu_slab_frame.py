@@ -108,7 +108,11 @@ def test_asynchronous_global_readback_on_slabs(ws):
         s.read_positions_begin(buf)
         s.run(4)
         s.read_positions_end()
-        return want, buf, s.read_positions()
+        later = s.read_positions()
+        s.read_positions_begin_owned()       # the same into the library's own page-locked double buffer
+        s.run(2)
+        s.read_positions_end()
+        return want, buf, later, s.read_positions_view().copy()
 
     w = ws.FluidWorker(pos, params)
     w.run(3)
@@ -116,8 +120,9 @@ def test_asynchronous_global_readback_on_slabs(ws):
     w.run(4)
     single7 = w.read_positions()
     w.close()
-    for want, buf, later in ws.slab.run_loopback_program(pos, params, 2, program):
+    for want, buf, later, owned in ws.slab.run_loopback_program(pos, params, 2, program):
         assert np.array_equal(want, single3) and np.array_equal(buf, single3) and np.array_equal(later, single7)
+        assert np.array_equal(owned, single7)
 
 
 def test_capacity_overrun_with_a_sync_after_every_step_still_fails_every_rank_at_the_same_step(ws):

@@ -177,6 +177,15 @@ class FluidWorker {
         check(ws_read_positions_begin(h_, reinterpret_cast<float *>(buf.data())));
     }
     void read_positions_end() { check(ws_read_positions_end(h_)); }
+    // ... or into the library's own page-locked double buffer (no buffer of the host's to pin): after _end, view() is the
+    // frame just read and stays untouched while the next frame's copy is in flight
+    void read_positions_begin_owned() { check(ws_read_positions_begin(h_, nullptr)); }
+    const Vec3 *read_positions_view()
+    {
+        const float *p = nullptr;
+        check(ws_read_positions_view(h_, &p));
+        return reinterpret_cast<const Vec3 *>(p);
+    }
     void pin(std::vector<Vec3> &buf) { check(ws_pin_host_buffer(h_, buf.data(), buf.size() * sizeof(Vec3))); }
     void unpin(std::vector<Vec3> &buf) { check(ws_unpin_host_buffer(h_, buf.data())); }
     // velocities.length() per particle: the input of update_particle_color, :489-502

@@ -344,6 +344,17 @@ class SlabWorker:
     def read_positions_end(self):
         self._check(self._L.ws_read_positions_end(self._h))
 
+    def read_positions_begin_owned(self):
+        """COLLECTIVE like read_positions_begin, into the library's own page-locked double buffer."""
+        self._L.ws_read_positions_begin.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self._L.ws_read_positions_begin(self._h, None))
+
+    def read_positions_view(self):
+        p = C.c_void_p()
+        self._L.ws_read_positions_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        self._check(self._L.ws_read_positions_view(self._h, C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(self.n_global, 3))
+
     def read_speeds(self):
         out = np.empty(self.n_global, np.float32)
         self._check(self._L.ws_read_speeds(self._h, out.ctypes.data))
