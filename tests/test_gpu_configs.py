@@ -132,12 +132,13 @@ def test_c4_in_four_slabs_matches_the_single_handle(ws, monkeypatch, overlap):
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
-def test_c5_in_eight_slabs_matches_the_single_handle(ws):
+@pytest.mark.parametrize("steps", [3, 190])
+def test_c5_in_eight_slabs_matches_the_single_handle(ws, steps):
     """BASELINE.json config 5 (67 108 864 particles) in its 8-GPU decomposition (eight x-slabs; loopback transport on the
-    one test GPU, ~60 GB of HBM): the host's global read returns, on the first and the last rank, id-ordered positions
-    bit-identical to the single handle's, and the slabs own all particles between them."""
+    one test GPU, ~100 GB of HBM): the host's global read returns, on the first and the last rank, id-ordered positions
+    bit-identical to the single handle's, and the slabs own all particles between them.  190 steps: into the rebound of
+    the collapsed cloud (a million migrants per slab and step, the far route by the hundred thousand)."""
     pos, params = ws.workloads.make_workload("c5", "cloud")
-    steps = 3
     w = ws.FluidWorker(pos, params)
     w.run(steps)
     want = w.read_positions()
@@ -151,3 +152,31 @@ def test_c5_in_eight_slabs_matches_the_single_handle(ws):
     res = ws.slab.run_loopback_program(pos, params, 8, program)
     assert sum(r[1] for r in res) == pos.shape[0]
     assert res[0][0] is True and res[7][0] is True
+
+
+def test_c4_in_four_slabs_into_the_rebound_matches_the_single_handle(ws):
+    """BASELINE.json config 4 in its four slabs, stepped INTO the rebound of the collapsed cloud (200 steps): by then more
+    than 300 000 particles leave a slab towards one neighbour per step and more than 100 000 cross several slabs at once
+    (the far route), the migration fill runs as its multi-kernel form, and the messages have grown with the fluid from a
+    few thousand records to hundreds of thousands -- with the DEFAULT capacities.  Positions on the first and the last
+    rank bit-identical to the single handle's.  (Rounds 1-3 stepped C4 in slabs for six steps; run further it overran.)"""
+    pos, params = ws.workloads.make_workload("c4", "cloud")
+    steps = 200
+    w = ws.FluidWorker(pos, params)
+    w.run(steps)
+    want = w.read_positions()
+    w.close()
+
+    def program(s, rank):
+        s.run(steps)
+        got = s.read_positions(want=(rank in (0, 3)))
+        st = s.stats()
+        return None if got is None else bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))), s.num_owned(), st
+
+    res = ws.slab.run_loopback_program(pos, params, 4, program)
+    assert sum(r[1] for r in res) == pos.shape[0]
+    assert res[0][0] is True and res[3][0] is True
+    assert max(r[2]["migration_peak"] for r in res) > 100000 and max(r[2]["far_peak"] for r in res) > 10000, [r[2] for r in res]
+    for r in res:
+        assert r[2]["migration_peak"] < r[2]["migration_capacity"] and r[2]["far_peak"] < r[2]["far_capacity"]
+        assert r[2]["halo_peak"] < r[2]["halo_capacity"]

@@ -232,3 +232,28 @@ def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
             assert st["migration_now"] < st["migration_capacity"] // 4 and st["halo_now"] < st["halo_capacity"]
             assert st["far_now"] < st["far_capacity"] // 16
     assert len({(st["migration_now"], st["halo_now"], st["far_now"]) for _, st in res}) == 1  # the same on every rank
+
+
+def test_four_slabs_through_the_collapse_and_rebound_of_c2_match_the_single_handle(ws):
+    """The benchmark trajectory, not a few quiet steps: C2 (262 144 particles) in four slabs through the collapse of the
+    cloud and its rebound (220 steps) -- migration by the ten thousand per step, the multi-kernel migration fill, message
+    sizes that follow the fluid up and down -- is the single handle's result bit for bit, with the DEFAULT capacities
+    (rounds 1-3 never stepped a multi-slab run this far: every multi-GPU benchmark configuration overran there)."""
+    pos, params = ws.workloads.make_workload("c2", "cloud")
+    steps, world = 220, 4
+    want = _single(ws, pos, params, steps)
+
+    def program(s, rank):
+        sizes = []
+        for k in range(steps // 20):
+            s.run(20)
+            sizes.append(s.stats()["migration_now"])
+        return s.read_vec("particles"), s.stats(), sizes, s.counters()
+
+    res = ws.slab.run_loopback_program(pos, params, world, program)
+    for rec, st, sizes, c in res:
+        for f in want.dtype.names:
+            assert np.array_equal(rec[f].view(np.uint32), want[f].view(np.uint32)), f
+        assert st["migration_peak"] <= st["migration_capacity"] and st["halo_peak"] <= st["halo_capacity"]
+        assert all(4096 <= x <= st["migration_capacity"] // 4 for x in sizes), sizes  # sized by the fluid, not the capacity
+    assert sum(c["left"] for _, _, _, c in res) > 10000
