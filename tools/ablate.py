@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer: time ONE step of each variant library from the SAME state (so that a variant whose results are not
 meant to be right -- an ablation -- cannot change the workload it is timed on).
-usage: ablate.py <warm steps> <lib> [<lib> ...]   (libs = names under tools/ab/)"""
+usage: ablate.py <warm steps> <lib> [<lib> ...]   (libs = names under tools/ab/; ABLATE_CONFIG=c4 for another configuration)"""
 import json
 import os
 import sys
@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import water_sandbox_amd as ws  # noqa: E402
 
 warm = int(sys.argv[1])
-pos, params = ws.workloads.make_workload("c3", "cloud")
+pos, params = ws.workloads.make_workload(os.environ.get("ABLATE_CONFIG", "c3"), "cloud")
 w = ws.FluidWorker(pos, params)
 w.run(warm)
 state = w.read_vec("particles")
@@ -29,5 +29,6 @@ for rep in range(2):
             for k, (t, c) in v.profile().items():
                 if c:
                     ms.setdefault(k, []).append(t / c)
+        over = v.stats()["mask_overflow"]
         v.close()
-        print(json.dumps({"lib": name, "warm": warm, "ms": {k: round(min(x), 4) for k, x in ms.items()}}), flush=True)
+        print(json.dumps({"lib": name, "warm": warm, "mask_overflow_per_step": over // 3, "ms": {k: round(min(x), 4) for k, x in ms.items()}}), flush=True)

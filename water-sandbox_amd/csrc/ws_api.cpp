@@ -744,7 +744,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
-    CREATE_HIP(hipMalloc(&h->id_tmp, (size_t)n * 4));
+    CREATE_HIP(hipMalloc(&h->id_tmp, (size_t)n * 4 + 16));  // k_reorder reads 16 bytes at a time
     if (h->variant == WS_VARIANT_LISTED) {
         h->mask.stride = n;
         CREATE_HIP(hipMalloc(&h->mask.words, (size_t)wsk_mask_words() * n * 4));

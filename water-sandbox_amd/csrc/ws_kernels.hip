@@ -481,6 +481,7 @@ void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id,
 // (simulation.wgsl:307).  After an upload (ws_create, ws_reset, ws_write_particles, a slab's first step) the stored
 // `cur.pred` is used instead: the caller's predicted positions are taken as they are.
 #define WS_LOOKAHEAD 0.02f  // 1. / 50., simulation.wgsl:3
+typedef uint32_t nd_u4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive words, 4-byte aligned
 template <bool RECOMPUTE_PRED>
 __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *__restrict__ slot_tmp,
                                                       const uint32_t *__restrict__ id_tmp,
@@ -497,11 +498,11 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     if (c == WS_DEAD) return;  // a stale slot after a migration overrun (the step is already flagged invalid)
     const uint32_t b = start[d.guard + c], e = start[d.guard + c + 1];
     uint32_t rank = 0;
-    for (uint32_t t = b; t < e; t += 4) {  // four cell-mates per trip: their loads go out together
-        const uint32_t a0 = id_tmp[t], a1 = id_tmp[min(t + 1u, e - 1u)], a2 = id_tmp[min(t + 2u, e - 1u)],
-                       a3 = id_tmp[min(t + 3u, e - 1u)];
-        rank += (a0 < id ? 1u : 0u) + ((t + 1u < e && a1 < id) ? 1u : 0u) + ((t + 2u < e && a2 < id) ? 1u : 0u) +
-                ((t + 3u < e && a3 < id) ? 1u : 0u);
+    for (uint32_t t = b; t < e; t += 4) {  // four cell-mates per trip from ONE 16-B load (id_tmp is padded by four words)
+        const nd_u4u a = *reinterpret_cast<const nd_u4u *>(id_tmp + t);
+        const uint32_t left = e - t;
+        rank += (a[0] < id ? 1u : 0u) + ((left > 1u && a[1] < id) ? 1u : 0u) + ((left > 2u && a[2] < id) ? 1u : 0u) +
+                ((left > 3u && a[3] < id) ? 1u : 0u);
     }
     const uint32_t dst = b + rank;
     const float4 p = cur.pos[i], v = cur.vel[i];
@@ -951,7 +952,6 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nt)
 
 typedef float nd_f4 __attribute__((ext_vector_type(4)));
 typedef float nd_f4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive floats, 4-byte aligned
-typedef uint32_t nd_u4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // Both ends of a run in ONE 16-byte load: the run of column cell `cc` is [start[cc - 1], start[cc + 2]), four
 // consecutive table entries (the texture addresser is the busiest unit of both neighbour kernels in the sparse state;
