@@ -1,8 +1,9 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04
-L=gpurun_out/r04/steady_reorder16.log
-(timeout -k 10 200 python3 tools/steady.py c3 5 20 base reorder16 base reorder16 &&
-timeout -k 10 200 python3 tools/steady.py c3 400 50 base reorder16 base reorder16 &&
-timeout -k 10 300 python3 tools/steady.py c4 400 50 base reorder16 base reorder16) > $L 2>&1
-echo "exit $?"; cat $L
+A=${STEADY_A:-reorder16}; B=${STEADY_B:-stagger}
+L=gpurun_out/r04/steady_${B}.log
+(timeout -k 10 200 python3 tools/steady.py c3 5 20 $A $B $A $B &&
+timeout -k 10 200 python3 tools/steady.py c3 60 20 $A $B $A $B &&
+timeout -k 10 200 python3 tools/steady.py c3 400 50 $A $B $A $B) > $L 2>&1
+echo "exit $?"; cut -c1-260 $L
