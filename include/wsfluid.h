@@ -235,21 +235,21 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  * contiguous particle ranges).  Interactions reach one cell, so a slab needs one ghost layer from
  * each x-neighbour.  ws_step on a slab handle enqueues, per step:
  *   hand particles whose predicted position left the slab to their new owner (migration: one send/recv with each
- *   neighbour, plus one small all-gather for the rare particle that crosses several slabs in a step) -> sort own
+ *   neighbour, plus one all-to-all for the particles that cross several slabs in a step and for the status words) -> sort own
  *   particles -> send the two boundary layers' records to the neighbours (halo A) -> K4 -> send their densities
  *   (halo B) -> K5+K6; with the halos on a second stream while the particles that need no ghosts compute.
  * ws_step never waits for the step it enqueues on a slab handle either (the one thing it may wait for is the status
  * table of the step enqueued two calls earlier -- a bounded run-ahead): every message has a fixed capacity known to both ends
  * (ghost_capacity and sizes derived from it) and carries its record count in a header; the owned count, the layer
  * ranges and the ghost counts stay on the device, kernels are launched over host-side upper bounds.  A capacity
- * overrun clamps, sets a sticky error bit that reaches every rank with the next step's all-gather, and makes ws_step
+ * overrun clamps, sets a sticky error bit that reaches every rank with the next step's all-to-all, and makes ws_step
  * return WS_ERR_OUT_OF_MEMORY on ALL ranks at the same step (two steps later), before any collective of that step --
  * no rank is left waiting in one.  ws_sync / ws_slab_read_particles / ws_slab_counters report the bits too, as soon
  * as this rank knows them -- which may be one or two steps before the other ranks do: such a report is information,
  * not the signal to stop; keep calling ws_step until IT fails (it does on every rank at the same step, and until
  * then it keeps issuing the step's collectives so that no peer waits alone).  ws_num_particles of a slab is exact
  * after ws_sync.
- * All data movement goes through the two transport callbacks below (bench.py uses the library's own RCCL
+ * All data movement goes through the three transport callbacks below (bench.py uses the library's own RCCL
  * transport, ws_rccl_transport_create; tests also drive them with torch.distributed and with an in-process
  * loopback).  The particle order inside a cell is canonical (by id), so an N-slab run reproduces the single-GPU
  * run bit for bit.  The reference has no multi-device path; this is the scale-out row of SURVEY.md 8(e). */
@@ -263,11 +263,17 @@ typedef struct ws_transport {
                     void *const recv_ptr[], const uint64_t recv_bytes[], void *stream);
     /* Stream-ordered all-gather of bytes_each DEVICE bytes per rank into recv_ptr[world_size * bytes_each]. */
     int (*allgather_dev)(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream);
+    /* Stream-ordered all-to-all of DEVICE buffers: bytes [r * bytes_each, (r + 1) * bytes_each) of send_ptr go to rank
+     * r, which stores them at [this rank * bytes_each, ...) of its recv_ptr; the segment a rank addresses to itself is
+     * copied too (RCCL: ncclAllToAll).  Once per step on the handle's stream: the per-destination messages for particles
+     * that cross more than one slab in a step, each headed by the sender's status words -- so every rank also ends up
+     * with every rank's status.  Required when world_size > 1. */
+    int (*alltoall_dev)(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream);
 } ws_transport;
 
 /* A ws_transport implemented inside the library with RCCL (ncclSend / ncclRecv groups with the two x-neighbours,
- * ncclAllGather for the count words), for hosts that have no communication layer of their own.  librccl is loaded
- * at run time.  Rank 0 draws a unique id and the host hands its 128 bytes to every rank (any out-of-band channel);
+ * ncclAllToAll for the far messages and the status words, ncclAllGather for the host's collective reads), for hosts
+ * that have no communication layer of their own.  librccl is loaded at run time.  Rank 0 draws a unique id and the host hands its 128 bytes to every rank (any out-of-band channel);
  * every rank then creates its transport -- a collective call -- on the device its slab will live on.  The
  * transport must outlive the slab handle created with it. */
 #define WS_RCCL_UNIQUE_ID_BYTES 128
@@ -276,7 +282,7 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
                                    ws_transport *out);
 void ws_rccl_transport_destroy(ws_transport *t);
 const char *ws_rccl_last_error(void);
-/* Communicators the transport drives: 2 = the step's two streams (migration / all-gather on the handle's stream, halos on
+/* Communicators the transport drives: 2 = the step's two streams (migration / all-to-all on the handle's stream, halos on
  * its communication stream) each keep to a communicator of their own (the second one is split off the first), so no
  * communicator ever sees operations from two streams; 1 = WS_RCCL_SINGLE_COMM=1 or an RCCL without ncclCommSplit. */
 uint32_t ws_rccl_transport_communicators(const ws_transport *t);
@@ -321,7 +327,7 @@ ws_status ws_slab_rebalance(ws_handle *h);
 ws_status ws_slab_balanced_cuts(const uint32_t *hist, uint32_t nx, uint32_t world_size, uint32_t *cuts_out);
 /* Migration counters of this slab since it was created (cumulative over ws_reset, ws_write_particles, a re-grid and a
  * re-cut), as of the last migration that has run (waits for enqueued steps): out[0] = particles owned now, out[1] = particles that left, out[2] = particles that arrived, out[3] = of
- * those that left, the ones that crossed more than one slab in a step (the all-gathered route).  The reference is a
+ * those that left, the ones that crossed more than one slab in a step (the all-to-all route).  The reference is a
  * single-GPU program and has no counterpart; diagnostics for the host and for the tests. */
 ws_status ws_slab_counters(ws_handle *h, uint64_t out[4]);
 
@@ -373,7 +379,7 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * (WS_FLAG_GRAPH); slab handles: out[5] = the most particles one of this slab's boundary layers has held since the last
  * load and out[6] = the halo capacity it must stay under (ws_device_cfg.ghost_capacity), out[7] = the most particles
  * that left towards one neighbour in one step and out[8] = the migration message's capacity, out[9] = the most that crossed
- * more than one slab in one step and out[10] = the far message's capacity; out[11..13] = the records the NEXT step's
+ * more than one slab towards ONE destination rank in one step and out[10] = the capacity of a far message (one per destination); out[11..13] = the records the NEXT step's
  * migration, halo and far messages will carry (sized from what every rank reported a few steps ago; the capacities
  * with WS_SLAB_FIXED_MESSAGES=1); the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);

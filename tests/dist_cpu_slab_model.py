@@ -32,7 +32,7 @@ ERR_MIGRATION, ERR_HALO = 1, 4
 class Protocol:
     """The slab step's message discipline (csrc/ws_slab.inc) on gloo: every message has a FIXED capacity known to
     both ends and carries its record count in a header; nothing is sized by a count only the sender knows.  An
-    overrun clamps and sets a sticky error bit, which reaches every rank with the per-step all-gather and is acted on
+    overrun clamps and sets a sticky error bit, which reaches every rank with the per-step all-to-all and is acted on
     LAG steps later by all ranks alike."""
     LAG = 2
 
@@ -69,15 +69,16 @@ class Protocol:
             got[key] = a[1:1 + int(a[0, 0]), :width]
         return got
 
-    def allgather_far(self, payload, n_owned, step):
-        """The small all-gathered message for particles that cross more than one slab, and -- in its headers --
-        every rank's owned count and error bits of this step."""
+    def alltoall_far(self, payload, dest, n_owned, step):
+        """The messages for particles that cross more than one slab -- one per destination rank, exchanged all-to-all -- and,
+        in their headers, every rank's owned count and error bits of this step (csrc/ws_slab.inc: alltoall_dev)."""
         width = payload.shape[1]
-        mine = self._message(payload, self.far_cap, width, n_owned, step, ERR_MIGRATION)
-        out = [torch.zeros_like(mine) for _ in range(self.world)]
-        dist.all_gather(out, mine)
-        self.tables[step] = np.stack([o.numpy()[0, :HDR] for o in out])
-        return [o.numpy()[1:1 + int(o.numpy()[0, 0]), :width] for o in out]
+        mine = torch.stack([self._message(payload[dest == r], self.far_cap, width, n_owned, step, ERR_MIGRATION) for r in range(self.world)])
+        got = torch.zeros_like(mine)
+        dist.all_to_all_single(got, mine)
+        got = got.numpy()
+        self.tables[step] = np.stack([got[q, 0, :HDR] for q in range(self.world)])
+        return [got[q, 1:1 + int(got[q, 0, 0]), :width] for q in range(self.world)]
 
     def gather_by_id(self, ids, payload, n_global):
         """The host's global reads on slab handles (csrc/ws_slab.inc slab_gather): ONE all-gather of the owned counts, ONE
@@ -214,13 +215,13 @@ def main():
         def packm(mask):
             return np.c_[ids[mask], state["position"][mask, :3], state["velocity"][mask, :3],
                          state["predicted_position"][mask, :3], state["density"][mask], state["acceleration"][mask, :3]].astype(np.float64)
-        # direct neighbours by send/recv; anything further through the small all-gathered message, tagged with its owner
+        # direct neighbours by send/recv; anything further in the message addressed to its owner (all-to-all)
         arr = proto.exchange(packm(dest == rank - 1), packm(dest == rank + 1), proto.mig_cap, len(state), step, ERR_MIGRATION)
         far = np.abs(dest - rank) > 1
-        far_all = proto.allgather_far(np.c_[packm(far), dest[far].astype(np.float64)], len(state), step)
+        far_all = proto.alltoall_far(packm(far), dest[far], len(state), step)
         keep = dest == rank
         state, ids = state[keep], ids[keep]
-        arrivals = [arr["left"], arr["right"]] + [a[a[:, -1] == rank, :-1] for q, a in enumerate(far_all) if q != rank]
+        arrivals = [arr["left"], arr["right"]] + [a for q, a in enumerate(far_all) if q != rank]
         for a in arrivals:
             if a is not None and len(a):
                 add = np.zeros(len(a), O.PARTICLE_DTYPE)

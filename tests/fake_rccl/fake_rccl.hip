@@ -1,5 +1,5 @@
 // fake_rccl.hip -- TEST INFRASTRUCTURE, never shipped and never a default: a stand-in for librccl that lets a ONE-GPU box
-// drive the library's RCCL transport (csrc/ws_rccl.cpp) with real peers.  It exports the ten nccl* symbols that transport
+// drive the library's RCCL transport (csrc/ws_rccl.cpp) with real peers.  It exports the eleven nccl* symbols that transport
 // binds; the "ranks" are host threads of one process on one GPU, and a message travels through a staging buffer in
 // device memory.  The transport finds it through WS_RCCL_LIBRARY (tests/test_gpu_fake_rccl.py sets it in a child
 // process); without that variable the library loads the real librccl and nothing here exists for it.
@@ -160,6 +160,43 @@ __global__ void __launch_bounds__(NT) fk_allgather(const uint32_t *__restrict__ 
     __hip_atomic_fetch_add(ag_ctl + A_DEPARTED, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ncclAllToAll (RCCL's own): the all-gather's rounds and counters (both are collectives of the same communicator, issued
+// in the same order by every rank), with W x W segments in the staging buffer: rank r's whole send buffer goes in at
+// [r W, (r + 1) W), segment (q W + r) comes out as what rank q addressed to rank r.  The byte count is noted with its
+// top bit set: a rank that calls the other collective in the same round is a size mismatch.
+__global__ void __launch_bounds__(NT) fk_alltoall(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t *staging, size_t nwords_each,
+                                                  uint32_t rank, uint32_t W, uint32_t *ag_ctl, uint32_t *seq, uint32_t *notes, uint32_t *wg_in,
+                                                  uint32_t *wg_out, uint32_t bytes, uint32_t *err, unsigned long long ticks)
+{
+    __shared__ uint32_t s_ok, s_round;
+    const uint32_t note = bytes | 0x80000000u;
+    if (threadIdx.x == 0) {
+        s_round = ld(seq);
+        s_ok = fk_spin(ag_ctl + A_DEPARTED, s_round * W, err, ticks) ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t round = s_round;
+    if (s_ok) fk_copy(staging + (size_t)rank * W * nwords_each, src, nwords_each * W, true);
+    if (fk_last(wg_in) && threadIdx.x == 0) {
+        st(notes + rank, note);
+        __threadfence();
+        __hip_atomic_fetch_add(ag_ctl + A_ARRIVED, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        uint32_t ok = fk_spin(ag_ctl + A_ARRIVED, round * W + W, err, ticks) ? 1u : 0u;
+        for (uint32_t r = 0; ok && r < W; r++)
+            if (ld(notes + r) != note) __hip_atomic_fetch_or(err, ERR_SIZE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (s_ok)
+        for (uint32_t q = 0; q < W; q++) fk_copy(dst + (size_t)q * nwords_each, staging + ((size_t)q * W + rank) * nwords_each, nwords_each, false);
+    if (!fk_last(wg_out) || threadIdx.x != 0) return;
+    st(seq, round + 1u);
+    __threadfence();
+    __hip_atomic_fetch_add(ag_ctl + A_DEPARTED, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct Channel {
     uint32_t *ctl = nullptr;
     char *staging = nullptr;
@@ -212,7 +249,7 @@ bool group_alloc(Group *g, int world)
 {
     g->world = world;
     g->chan_cap = env_bytes("FAKE_RCCL_CHANNEL_BYTES", (size_t)16 << 20);
-    g->ag_cap = env_bytes("FAKE_RCCL_ALLGATHER_BYTES", (size_t)128 << 20);
+    g->ag_cap = env_bytes("FAKE_RCCL_ALLGATHER_BYTES", (size_t)512 << 20);  // (an all-to-all stages world x world segments)
     g->ticks = (unsigned long long)env_bytes("FAKE_RCCL_TIMEOUT_MS", 3000) * 100000ull;
     g->to_right.resize(world);
     g->to_left.resize(world);
@@ -315,7 +352,7 @@ int flush_ops()
     return rc;
 }
 
-unsigned long long g_calls[3];  // send / recv operations, all-gathers, communicators
+unsigned long long g_calls[4];  // send / recv operations, all-gathers, communicators, all-to-alls
 unsigned long long *calls() { return g_calls; }
 
 }  // namespace
@@ -441,6 +478,23 @@ int ncclAllGather(const void *sendbuf, void *recvbuf, size_t count, int dtype, v
     return hipGetLastError() == hipSuccess ? OK : UNHANDLED;
 }
 
+int ncclAllToAll(const void *sendbuf, void *recvbuf, size_t count, int dtype, void *comm, hipStream_t s)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    if (dtype != 1 || !c) return INVALID_ARG;
+    Group *g = c->g;
+    const uint32_t W = (uint32_t)g->world;
+    if (count * W * W > g->ag_cap || (count & 3u) || count >= ((size_t)1 << 31)) return INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        calls()[3]++;
+    }
+    hipLaunchKernelGGL(fk_alltoall, dim3(NB), dim3(NT), 0, s, (const uint32_t *)sendbuf, (uint32_t *)recvbuf, (uint32_t *)g->ag_staging, count / 4,
+                       (uint32_t)c->rank, W, g->ag_ctl, g->ag_seq + c->rank, g->ag_cnt, g->ag_wg + c->rank, g->ag_wg2 + c->rank, (uint32_t)count,
+                       g->err, g->ticks);
+    return hipGetLastError() == hipSuccess ? OK : UNHANDLED;
+}
+
 const char *ncclGetErrorString(int rc)
 {
     switch (rc) {
@@ -468,10 +522,10 @@ uint32_t fake_rccl_errors(void)
 }
 
 // test hook: calls served since the library was loaded (proof that the transport really went through here)
-void fake_rccl_calls(unsigned long long out[3])
+void fake_rccl_calls(unsigned long long out[4])
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int i = 0; i < 3; i++) out[i] = g_calls[i];
+    for (int i = 0; i < 4; i++) out[i] = g_calls[i];
 }
 
 }  // extern "C"

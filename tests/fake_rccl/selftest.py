@@ -1,6 +1,10 @@
 """Stand-alone exercise of tests/libfakerccl.so (no product code): `world` host threads, one torch stream each, all-gathers
-of alternating sizes and neighbour send / recv groups with per-rank delays; every result is checked on the host.
-    python3 tests/fake_rccl/selftest.py [world] [rounds]"""
+of alternating sizes, all-to-alls and neighbour send / recv groups with per-rank delays; every result is checked on the host.
+    python3 tests/fake_rccl/selftest.py [world] [rounds]
+With four or more ranks set GPU_MAX_HW_QUEUES=8: the runtime multiplexes the streams of one priority onto four hardware
+queues, and two ranks' torch streams that share one wait for each other's spinning kernel until the stand-in's time limit
+(world 4: 3 000 bad results with the default, none with eight queues).  The product's own slab streams (two per rank, of
+different priorities, created by the library) have not collided in the 4-rank cases of tests/test_gpu_fake_rccl.py."""
 import ctypes as C
 import os
 import random
@@ -20,6 +24,7 @@ class Uid(C.Structure):
 
 L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
 L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+L.ncclAllToAll.argtypes = L.ncclAllGather.argtypes
 L.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 L.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 L.fake_rccl_errors.restype = C.c_uint32
@@ -68,6 +73,11 @@ def main():
                             bad.append(("raw allgather", r, k, q, int(hh[q, 0]), int(hh[q, n - 1])))
                     assert hip.hipFree(raw_dst) == 0
                 assert L.ncclAllGather(src.data_ptr(), dst.data_ptr(), n * 4, 1, comm, st.cuda_stream) == 0
+                # all-to-all: segment q of the send buffer is addressed to rank q
+                a = 64 + 16 * (k % 3)
+                a_src = (torch.arange(world, dtype=torch.int32, device="cuda").repeat_interleave(a) * 131 + r * 10007 + k)
+                a_dst = torch.zeros((a * world,), dtype=torch.int32, device="cuda")
+                assert L.ncclAllToAll(a_src.data_ptr(), a_dst.data_ptr(), a * 4, 1, comm, st.cuda_stream) == 0
                 # neighbour exchange, as the slab step does it (one group, both directions)
                 m = 1024 + 16 * (k % 5)
                 sl = torch.full((m,), r * 7 + k, dtype=torch.int32, device="cuda")
@@ -88,6 +98,10 @@ def main():
                 for q in range(world):
                     if not (bool((h[q, : n - 1] == q * 1000003 + k).all()) and int(h[q, n - 1]) == k):
                         bad.append(("allgather", r, k, q, int(h[q, 0]), int(h[q, n - 1])))
+                ha = a_dst.cpu().view(world, a)
+                for q in range(world):  # what rank q addressed to me
+                    if not bool((ha[q] == r * 131 + q * 10007 + k).all()):
+                        bad.append(("alltoall", r, k, q, int(ha[q, 0])))
                 if r > 0 and not bool((rl.cpu() == (r - 1) * 11 + k).all()):
                     bad.append(("recv from left", r, k, int(rl[0])))
                 if r + 1 < world and not bool((rr.cpu() == (r + 1) * 7 + k).all()):

@@ -1,6 +1,6 @@
 """Child process of tests/test_gpu_fake_rccl.py: WS_RCCL_LIBRARY names the tests' stand-in for librccl (tests/fake_rccl/),
 so ws_rccl_transport_create binds IT -- and the library's RCCL transport (csrc/ws_rccl.cpp: peer arithmetic, segment
-order, grouped send / recv, the all-gather, two communicators bound to two streams, ncclCommSplit) runs with real
+order, grouped send / recv, the all-to-all and the all-gather, two communicators bound to two streams, ncclCommSplit) runs with real
 peers: `world` slab handles in this one process, one host thread each, on the one GPU.  Prints one JSON object."""
 import ctypes as C
 import json
@@ -19,7 +19,7 @@ fake.fake_rccl_errors.restype = C.c_uint32
 
 
 def calls():
-    out = (C.c_ulonglong * 3)()
+    out = (C.c_ulonglong * 4)()
     fake.fake_rccl_calls(out)
     return [int(x) for x in out]
 
@@ -107,6 +107,7 @@ def main():
         case = {"world": world, "graph": graph, "fake_errors": err,
                 "communicators": [c for _, c in res],
                 "sendrecv_ops": after[0] - before[0], "allgathers": after[1] - before[1], "new_communicators": after[2] - before[2],
+                "alltoalls": after[3] - before[3],
                 "graph_steps": [r[0][2]["graph_steps"] for r in res],
                 "migrated": sum(r[0][3]["left"] for r in res),
                 "mid_frame_positions_identical": [bool(np.array_equal(r[0][1], want_mid)) for r in res],

@@ -348,7 +348,8 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
                       uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
-                      uint32_t *sendR, uint32_t *far_send);
+                      uint32_t *sendR, uint32_t *far_send, uint32_t far_next);
+void wsk_far_seal(hipStream_t s, uint32_t world, uint32_t far_cur, uint32_t *far_send, uint32_t *dyn);
 void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
                    uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities);
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,

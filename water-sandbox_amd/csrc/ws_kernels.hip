@@ -718,15 +718,17 @@ __device__ __forceinline__ void density_store(float density, float near_density,
 // message header: 8 words in front of every fixed-capacity message
 //   [0] records in the message   [1] sender's sticky error bits   [2] sender's owned count   [3] step stamp
 //   [4] the most records either of the sender's two migration messages of the previous exchange wanted to carry
-//   [5] the larger of the sender's two boundary-layer populations at the previous step's halo   [6..7] reserved
-// ([1..5] matter in the all-gathered far message only: its headers are the per-step status table of all ranks; from
-// [4] / [5] every rank sizes the next steps' messages -- the same table everywhere, hence the same sizes)
+//   [5] the larger of the sender's two boundary-layer populations at the previous step's halo
+//   [6] the most records any ONE of the sender's far messages of this exchange wanted to carry   [7] reserved
+// ([1..6] matter in the far messages only -- one per destination rank, exchanged all-to-all, each headed by the same
+// status words: their headers are the per-step status table of all ranks; from [4] / [5] / [6] every rank sizes the
+// next steps' messages -- the same table everywhere, hence the same sizes)
 #define WS_HDR_WORDS 8u
 
 // The particle in slot i (not in the histogram, its cell id already WS_DEAD) left the slab: write its 64-byte record
-// {pos+id, vel, pred, destination} into the message for its route -- left neighbour, right neighbour, or the small
-// all-gathered "far" message for a particle that crosses more than one slab in a step -- and remember the hole it
-// leaves.  A message's record count lives in its header word 0 and is counted there directly (the receiver clamps
+// {pos+id, vel, pred, destination} into the message for its route -- left neighbour, right neighbour, or the "far"
+// message addressed to its destination rank (one per rank, laid end to end at the stride of the size the next exchange
+// will have: a particle that crosses more than one slab in a step) -- and remember the hole it leaves.  A message's record count lives in its header word 0 and is counted there directly (the receiver clamps
 // it to the capacity; the other header words were written by the previous k_migrate_fill).  Order is free
 // everywhere here: the sort is canonical.
 __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint32_t i, float4 pos, float4 vel, float4 pred)
@@ -744,7 +746,8 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
     } else if (dest == m.me + 1u) {
         msg = m.sendR; cap = mig_cap;
     } else {
-        msg = m.far; cap = d.far_limit ? min(d.far_limit, m.far_cap) : m.far_cap;
+        cap = d.far_limit ? min(d.far_limit, m.far_cap) : m.far_cap;
+        msg = m.far + (size_t)min(dest, m.world - 1u) * (WS_HDR_WORDS + (size_t)cap * 16u);
         atomicAdd(&m.dyn[DY_FAR], 1u);
     }
     const uint32_t slot = atomicAdd(&msg[0], 1u);
@@ -1506,6 +1509,43 @@ void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cu
     if (d.n) hipLaunchKernelGGL(k_migrate_mark, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, cid_cur, count);
 }
 
+// The headers of the `world` far messages of the next exchange (one per destination, `far_next` records each): no
+// records yet, and the same status words in all of them.  (halo_now: the previous step's boundary-layer population --
+// this step's halo has not been packed yet.)  Word 6 is k_far_seal's.
+__device__ __forceinline__ void far_headers(uint32_t *__restrict__ far_send, uint32_t world, uint32_t far_next, uint32_t err,
+                                            uint32_t n_owned, uint32_t stamp, uint32_t wanted_mig, uint32_t halo_now)
+{
+    const size_t words = WS_HDR_WORDS + (size_t)far_next * 16u;
+    for (uint32_t r = 0; r < world; r++) {
+        uint32_t *hdr = far_send + r * words;
+        hdr[0] = 0;
+        hdr[1] = err;
+        hdr[2] = n_owned;
+        hdr[3] = stamp;
+        hdr[4] = wanted_mig;
+        hdr[5] = halo_now;
+        hdr[6] = 0;
+        hdr[7] = 0;
+    }
+}
+
+// Right before the far messages travel: the largest of this rank's `world` record counts into word 6 of every header
+// (the receivers see only the count of the message addressed to them; the sizes of the next steps' messages must come
+// out the same on every rank, so they are derived from a number every rank receives).  far_cur = records per message.
+__global__ void k_far_seal(uint32_t world, uint32_t far_cur, uint32_t *__restrict__ far_send, uint32_t *__restrict__ dyn)
+{
+    const size_t words = WS_HDR_WORDS + (size_t)far_cur * 16u;
+    uint32_t most = 0;
+    for (uint32_t r = 0; r < world; r++) most = max(most, far_send[r * words]);
+    for (uint32_t r = 0; r < world; r++) far_send[r * words + 6] = most;
+    dyn[DY_PEAK_FAR] = max(dyn[DY_PEAK_FAR], most);
+}
+
+void wsk_far_seal(hipStream_t s, uint32_t world, uint32_t far_cur, uint32_t *far_send, uint32_t *dyn)
+{
+    hipLaunchKernelGGL(k_far_seal, dim3(1), dim3(1), 0, s, world, far_cur, far_send, dyn);
+}
+
 // Migration, part 2 (ONE workgroup; a step moves a few thousand particles at most): count the arrivals, fix the new
 // owned count, then close the holes.  The owned range shrinks / grows from n_old to n_new.  Targets = holes below
 // n_new (+ the new slots when growing); sources = arrivals (tagged with their message in the top two bits) +
@@ -1522,13 +1562,14 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
                                                                  uint32_t *__restrict__ count,
                                                                  uint32_t *__restrict__ status_ring, uint32_t status_slots,
                                                                  uint32_t hole_cap, uint32_t *__restrict__ sendL,
-                                                                 uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send)
+                                                                 uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send,
+                                                                 uint32_t far_next)
 {
     __shared__ uint32_t s_far, s_ntgt, s_nsrc, s_nnew, s_nold, s_arr;
     const uint32_t tid = threadIdx.x;
     const uint32_t step = dyn[DY_STEP];  // (nobody writes it before the last barrier below)
     uint32_t *status = status_ring + (size_t)(step % status_slots) * world * WS_HDR_WORDS;
-    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;  // words per rank in the gathered far buffer
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;  // words per sending rank in the received far buffer
     const bool left = me > 0, right = me + 1 < world;
     if (tid == 0) {
         s_far = 0;
@@ -1536,7 +1577,8 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         s_nsrc = 0;
     }
     __syncthreads();
-    // far arrivals: records of other ranks' far messages addressed to this rank
+    // far arrivals: the records of the far messages the other ranks addressed to this one (the destination test is
+    // always true since the far messages are per destination; it costs nothing and catches a transport that mixes them up)
     for (uint32_t t = tid; t < world * far_cap; t += WS_FILL_THREADS) {
         const uint32_t q = t / far_cap, k = t % far_cap;
         if (q == me) continue;
@@ -1630,20 +1672,14 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         dyn[DY_LEFT] += leave;
         const uint32_t wanted = max(sendL[0], sendR[0]);  // (the counts of the messages just exchanged, clamped or not)
         dyn[DY_PEAK_MIG] = max(dyn[DY_PEAK_MIG], wanted);
-        dyn[DY_PEAK_FAR] = max(dyn[DY_PEAK_FAR], far_all[(size_t)me * far_words]);  // (what this rank's far message wanted to carry)
-        // the three outgoing migration messages of the NEXT step: counts back to zero (migrate_out counts in
-        // place), and the status words every rank will read from the far message's header: sticky error bits, the
-        // owned count and the step they describe
+        // the outgoing migration messages of the NEXT step: counts back to zero (migrate_out counts in place), and
+        // the status words every rank will read from the header of the far message addressed to it: sticky error
+        // bits, the owned count and the step they describe
         sendL[0] = 0;
         sendR[0] = 0;
         sendL[3] = step + 1u;
         sendR[3] = step + 1u;
-        far_send[0] = 0;
-        far_send[1] = dyn[DY_ERR];
-        far_send[2] = n_new;
-        far_send[3] = step + 1u;
-        far_send[4] = wanted;
-        far_send[5] = dyn[DY_HALO_NOW];  // the previous step's halo (this step's has not been packed yet)
+        far_headers(far_send, world, far_next, dyn[DY_ERR], n_new, step + 1u, wanted, dyn[DY_HALO_NOW]);
         dyn[DY_HALO_NOW] = 0;
     }
 }
@@ -1792,11 +1828,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_fill_apply(WsDev d, const uint32_t
     }
 }
 
-__global__ void k_fill_finish(uint32_t me, uint32_t *__restrict__ dyn, const uint32_t *__restrict__ far_all, uint32_t far_cap,
-                              uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR, uint32_t *__restrict__ far_send)
+__global__ void k_fill_finish(uint32_t world, uint32_t *__restrict__ dyn, uint32_t *__restrict__ sendL, uint32_t *__restrict__ sendR,
+                              uint32_t *__restrict__ far_send, uint32_t far_next)
 {
     const uint32_t step = dyn[DY_STEP];
-    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
     dyn[DY_N] = dyn[DY_F_NNEW];
     dyn[DY_STEP] = step + 1u;
     dyn[DY_NHOLE] = 0;
@@ -1805,17 +1840,11 @@ __global__ void k_fill_finish(uint32_t me, uint32_t *__restrict__ dyn, const uin
     dyn[DY_F_FAR] = 0;
     const uint32_t wanted = max(sendL[0], sendR[0]);
     dyn[DY_PEAK_MIG] = max(dyn[DY_PEAK_MIG], wanted);
-    dyn[DY_PEAK_FAR] = max(dyn[DY_PEAK_FAR], far_all[(size_t)me * far_words]);
     sendL[0] = 0;
     sendR[0] = 0;
     sendL[3] = step + 1u;
     sendR[3] = step + 1u;
-    far_send[0] = 0;
-    far_send[1] = dyn[DY_ERR];
-    far_send[2] = dyn[DY_F_NNEW];
-    far_send[3] = step + 1u;
-    far_send[4] = wanted;
-    far_send[5] = dyn[DY_HALO_NOW];
+    far_headers(far_send, world, far_next, dyn[DY_ERR], dyn[DY_F_NNEW], step + 1u, wanted, dyn[DY_HALO_NOW]);
     dyn[DY_HALO_NOW] = 0;
 }
 
@@ -1823,17 +1852,18 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
                       uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
-                      uint32_t *sendR, uint32_t *far_send)
+                      uint32_t *sendR, uint32_t *far_send, uint32_t far_next)
 {
-    // (mig_cap / far_cap: the records this step's messages carry -- the host's current limits, not the buffers' capacities)
+    // (mig_cap / far_cap: the records this step's messages carry -- the host's current limits, not the buffers' capacities;
+    // far_next: the records each far message of the NEXT exchange will carry, the stride the new headers are written at)
     const uint64_t volume = 2ull * mig_cap + (uint64_t)world * far_cap;
     if (volume <= 49152ull) {
         hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
                            mig_cap, far_all, far_cap, tgt, src, cur, cid_cur, count, status_ring, status_slots, hole_cap, sendL,
-                           sendR, far_send);
+                           sendR, far_send, far_next);
         return;
     }
-    const uint32_t b_leave = (uint32_t)std::min<uint64_t>(hole_cap, 2ull * mig_cap + far_cap);
+    const uint32_t b_leave = (uint32_t)std::min<uint64_t>(hole_cap, volume);  // (as many can have left as the messages carry)
     const uint32_t b_arr = (uint32_t)std::min<uint64_t>(volume, 0x3FFFFFFFull);
     hipLaunchKernelGGL(k_fill_count, dim3(cdiv(std::max(world * far_cap, world), WS_BLOCK)), dim3(WS_BLOCK), 0, s, world, me, dyn, recvL,
                        recvR, far_all, far_cap, status_ring, status_slots);
@@ -1843,7 +1873,7 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
                        far_all, far_cap, tgt, src, cid_cur, b_leave, b_arr, mig_cap);
     hipLaunchKernelGGL(k_fill_apply, dim3(cdiv((uint32_t)std::min<uint64_t>((uint64_t)b_leave + b_arr, 0x7FFFFFFFull), WS_BLOCK)),
                        dim3(WS_BLOCK), 0, s, d, dyn, recvL, recvR, far_all, far_cap, tgt, src, cur, cid_cur, count);
-    hipLaunchKernelGGL(k_fill_finish, dim3(1), dim3(1), 0, s, me, dyn, far_all, far_cap, sendL, sendR, far_send);
+    hipLaunchKernelGGL(k_fill_finish, dim3(1), dim3(1), 0, s, world, dyn, sendL, sendR, far_send, far_next);
 }
 
 // Halo messages.  A: [header | cell-start slice of the boundary layer (rowy + 1 words, padded to 4) | its 32-byte

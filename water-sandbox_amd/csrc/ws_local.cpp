@@ -122,6 +122,29 @@ int local_allgather(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t by
     return rc;
 }
 
+// segment r of every rank's send buffer is what that rank addresses to rank r
+int local_alltoall(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream)
+{
+    LocalTransport *t = static_cast<LocalTransport *>(ctx);
+    LocalHub *hub = t->hub;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        hub->fail_all();
+        return 1;
+    }
+    hub->offer[t->rank].gather_ptr = send_ptr;
+    if (!hub->barrier()) return 2;
+    int rc = 0;
+    for (uint32_t r = 0; r < hub->world && !rc; r++)
+        if (hipMemcpyAsync(static_cast<char *>(recv_ptr) + (size_t)r * bytes_each,
+                           static_cast<const char *>(hub->offer[r].gather_ptr) + (size_t)t->rank * bytes_each, (size_t)bytes_each,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess)
+            rc = 4;
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = 5;
+    if (!hub->barrier()) return 2;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -148,6 +171,7 @@ ws_status ws_local_transport_create(void *hub, uint32_t rank, ws_transport *out)
     out->ctx = t;
     out->sendrecv = local_sendrecv;
     out->allgather_dev = local_allgather;
+    out->alltoall_dev = local_alltoall;
     return WS_OK;
 }
 

@@ -1,5 +1,6 @@
 // ws_rccl.cpp -- a ws_transport made of RCCL calls issued by the library itself (no host-language callbacks in
-// the step): ncclSend / ncclRecv groups with the two x-neighbours over xGMI, ncclAllGather for the few count words.
+// the step): ncclSend / ncclRecv groups with the two x-neighbours over xGMI, ncclAllToAll for the per-destination far
+// messages (whose headers are the status words), ncclAllGather for the host's collective reads.
 // RCCL is loaded at run time (dlopen), so the library has no link-time dependency on it and single-GPU use
 // never touches it.  The host distributes rank 0's unique id (128 bytes) by whatever means it has.
 #include "wsfluid.h"
@@ -32,6 +33,7 @@ struct RcclApi {
     int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
+    int (*AllToAll)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;  // RCCL's own (not in NCCL)
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -68,7 +70,8 @@ bool load_rccl()
         const bool ok = sym(g_api.GetUniqueId, "ncclGetUniqueId") && sym(g_api.CommInitRank, "ncclCommInitRank") &&
                         sym(g_api.CommDestroy, "ncclCommDestroy") && sym(g_api.GroupStart, "ncclGroupStart") &&
                         sym(g_api.GroupEnd, "ncclGroupEnd") && sym(g_api.Send, "ncclSend") && sym(g_api.Recv, "ncclRecv") &&
-                        sym(g_api.AllGather, "ncclAllGather") && sym(g_api.GetErrorString, "ncclGetErrorString");
+                        sym(g_api.AllGather, "ncclAllGather") && sym(g_api.AllToAll, "ncclAllToAll") &&
+                        sym(g_api.GetErrorString, "ncclGetErrorString");
         if (!ok) {
             dlclose(g_api.lib);
             g_api.lib = nullptr;
@@ -139,6 +142,14 @@ int rccl_allgather(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t byt
     return check(t, g_api.AllGather(send_ptr, recv_ptr, (size_t)bytes_each, NCCL_UINT8, t->on(s), s), "ncclAllGather");
 }
 
+// ws_transport::alltoall_dev: segment r of the send buffer to rank r, its segment for this rank into segment r here
+int rccl_alltoall(void *ctx, const void *send_ptr, void *recv_ptr, uint64_t bytes_each, void *stream)
+{
+    RcclTransport *t = static_cast<RcclTransport *>(ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return check(t, g_api.AllToAll(send_ptr, recv_ptr, (size_t)bytes_each, NCCL_UINT8, t->on(s), s), "ncclAllToAll");
+}
+
 }  // namespace
 
 extern "C" {
@@ -182,6 +193,7 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
     out->ctx = t;
     out->sendrecv = rccl_sendrecv;
     out->allgather_dev = rccl_allgather;
+    out->alltoall_dev = rccl_alltoall;
     return WS_OK;
 }
 

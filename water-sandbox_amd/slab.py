@@ -6,9 +6,9 @@ library (csrc/ws_slab.inc); this module supplies the transports it calls and a t
 
 Transports:
   NativeRcclTransport the library's own RCCL transport (csrc/ws_rccl.cpp): ncclSend / ncclRecv groups
-                      with the two x-neighbours + ncclAllGather, issued from C++ -- no Python in the
+                      with the two x-neighbours + ncclAllToAll / ncclAllGather, issued from C++ -- no Python in the
                       step.  This is what bench.py uses.
-  TorchDistTransport  the same two callbacks on torch.distributed (RCCL or, in the tests, gloo).
+  TorchDistTransport  the same three callbacks on torch.distributed (RCCL or, in the tests, gloo).
   LoopbackHub         several slabs inside ONE process on ONE GPU, one host thread per slab,
                       device-to-device copies.  Lets the one-GPU test box exercise the whole slab
                       protocol (ghost indexing, migration, bit-exactness against one GPU).
@@ -28,7 +28,8 @@ ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_u
 
 
 class WsTransport(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_dev", ALLGATHER_DEV_T)]
+    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_dev", ALLGATHER_DEV_T),
+                ("alltoall_dev", ALLGATHER_DEV_T)]  # (the same signature)
 
 
 def assign(params, positions, world_size):
@@ -48,7 +49,7 @@ class _TransportBase:
 
     def __init__(self):
         self.error = None
-        self._thunks = (SENDRECV_T(self._c_sendrecv), ALLGATHER_DEV_T(self._c_allgather_dev))
+        self._thunks = (SENDRECV_T(self._c_sendrecv), ALLGATHER_DEV_T(self._c_allgather_dev), ALLGATHER_DEV_T(self._c_alltoall_dev))
         self.struct = WsTransport(None, *self._thunks)
 
     def _guard(self, fn, *a):
@@ -66,6 +67,9 @@ class _TransportBase:
 
     def _c_allgather_dev(self, ctx, sp, rp, nbytes, stream):
         return self._guard(self.allgather_dev, sp, rp, nbytes, stream)
+
+    def _c_alltoall_dev(self, ctx, sp, rp, nbytes, stream):
+        return self._guard(self.alltoall_dev, sp, rp, nbytes, stream)
 
 
 # ------------------------------------------------------------------------------------------
@@ -140,6 +144,19 @@ class TorchDistTransport(_TransportBase):
         else:  # gloo (tests): list form, fenced
             self._fence()
             self.dist.all_gather(list(dst.view(self.world, nbytes).unbind(0)), src, group=self.data_group)
+            self._fence()
+
+    def alltoall_dev(self, sp, rp, nbytes, stream):
+        src = self._tensor(sp, nbytes * self.world)
+        dst = self._tensor(rp, nbytes * self.world)
+        if self.stream_ordered:
+            with self._on(stream):
+                self.dist.all_to_all_single(dst, src, group=self.data_group)
+        else:  # gloo (tests): through host memory, fenced
+            self._fence()
+            host = self.torch.empty(nbytes * self.world, dtype=self.torch.uint8)
+            self.dist.all_to_all_single(host, src.cpu(), group=self.data_group)
+            dst.copy_(host)
             self._fence()
 
 
@@ -272,6 +289,16 @@ class _LoopbackTransport(_TransportBase):
         hub.barrier.wait()
         for r in range(self.world):
             hub.copy(rp + r * nbytes, hub.slots[r], nbytes, stream)
+        hub.done(stream)
+        hub.barrier.wait()
+
+    def alltoall_dev(self, sp, rp, nbytes, stream):
+        hub = self.hub
+        hub.hip.hipStreamSynchronize(stream)
+        hub.slots[self.rank] = sp
+        hub.barrier.wait()
+        for r in range(self.world):  # what rank r addressed to me
+            hub.copy(rp + r * nbytes, hub.slots[r] + self.rank * nbytes, nbytes, stream)
         hub.done(stream)
         hub.barrier.wait()
 
