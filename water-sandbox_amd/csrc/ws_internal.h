@@ -89,10 +89,12 @@ enum {
     WS_DYN_ERR_CAPACITY = 2u,   // owned count would exceed the slab's capacity
     WS_DYN_ERR_HALO = 4u,       // a boundary layer holds more particles than a halo message
     WS_DYN_ERR_GHOSTS = 8u,     // more ghosts than the ghost range holds
-    WS_DYN_ERR_STAMP = 16u      // a message stamped with another step arrived: the transport delivered out of order
+    WS_DYN_ERR_STAMP = 16u,     // a message stamped with another step arrived: the transport delivered out of order
+    WS_DYN_ERR_PRED = 32u       // an uploaded particle had to migrate with a predicted position its record cannot reproduce
 };
 enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LATE_RIGHT = 3, WS_RANGE_LATE_BOTH = 4 };
 #define WS_HDR_WORDS_HOST 8u  // words of a message header (ws_kernels.hip WS_HDR_WORDS)
+#define WS_MIG_REC_WORDS_HOST 8u  // = WS_MIG_REC_WORDS of ws_kernels.hip: {pos, id}, {vel, 0}
 #define WS_HDR_UNKNOWN 0xFFFFFFFFu  // header words 4 / 5 before the first migration / halo of a particle set has been counted
 
 // density / force kernel family (WS_VARIANT=simple in the environment, for A/B tests)

@@ -724,9 +724,13 @@ __device__ __forceinline__ void density_store(float density, float near_density,
 // status words: their headers are the per-step status table of all ranks; from [4] / [5] / [6] every rank sizes the
 // next steps' messages -- the same table everywhere, hence the same sizes)
 #define WS_HDR_WORDS 8u
+// A migrating particle travels as 32 bytes: {position, id} and {velocity, 0}.  Its predicted position is not sent: it is
+// position + velocity * look-ahead of exactly these values (simulation.wgsl:307), the receiver computes the same bits
+// (as k_reorder does every step), and its destination is the message it travels in.
+#define WS_MIG_REC_WORDS 8u
 
-// The particle in slot i (not in the histogram, its cell id already WS_DEAD) left the slab: write its 64-byte record
-// {pos+id, vel, pred, destination} into the message for its route -- left neighbour, right neighbour, or the "far"
+// The particle in slot i (not in the histogram, its cell id already WS_DEAD) left the slab: write its 32-byte record
+// {pos+id, vel} into the message for its route -- left neighbour, right neighbour, or the "far"
 // message addressed to its destination rank (one per rank, laid end to end at the stride of the size the next exchange
 // will have: a particle that crosses more than one slab in a step) -- and remember the hole it leaves.  A message's record count lives in its header word 0 and is counted there directly (the receiver clamps
 // it to the capacity; the other header words were written by the previous k_migrate_fill).  Order is free
@@ -747,7 +751,7 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
         msg = m.sendR; cap = mig_cap;
     } else {
         cap = d.far_limit ? min(d.far_limit, m.far_cap) : m.far_cap;
-        msg = m.far + (size_t)min(dest, m.world - 1u) * (WS_HDR_WORDS + (size_t)cap * 16u);
+        msg = m.far + (size_t)min(dest, m.world - 1u) * (WS_HDR_WORDS + (size_t)cap * WS_MIG_REC_WORDS);
         atomicAdd(&m.dyn[DY_FAR], 1u);
     }
     const uint32_t slot = atomicAdd(&msg[0], 1u);
@@ -755,11 +759,9 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
         atomicOr(&m.dyn[DY_ERR], WS_DYN_ERR_MIGRATION);
         return;
     }
-    float4 *rec = reinterpret_cast<float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)slot;
+    float4 *rec = reinterpret_cast<float4 *>(msg + WS_HDR_WORDS) + 2 * (size_t)slot;
     rec[0] = pos;
     rec[1] = vel;
-    rec[2] = pred;
-    rec[3] = make_float4(__uint_as_float(dest), 0.f, 0.f, 0.f);
 }
 
 // K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
@@ -1501,7 +1503,13 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, WsSoA cur, u
     if (c >= rowy && c < (uint32_t)(d.dim[0] - 1) * rowy) return;
     atomicSub(&count[c], 1u);
     cid_cur[i] = WS_DEAD;
-    migrate_out(d, *d.mig, i, cur.pos[i], cur.vel[i], cur.pred[i]);
+    const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
+    // (loads hand every particle to the slab its PREDICTED position lies in, so nothing leaves here unless the host's own
+    // assignment at ws_slab_create disagrees with the device's -- at rest.  A migration record does not carry the
+    // predicted position: one that the receiver could not reproduce must not travel silently.)
+    if (q.x != p.x + v.x * WS_LOOKAHEAD || q.y != p.y + v.y * WS_LOOKAHEAD || q.z != p.z + v.z * WS_LOOKAHEAD)
+        atomicOr(&d.mig->dyn[DY_ERR], WS_DYN_ERR_PRED);
+    migrate_out(d, *d.mig, i, p, v, q);
 }
 
 void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cur, uint32_t *count)
@@ -1515,7 +1523,7 @@ void wsk_migrate_mark(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid_cu
 __device__ __forceinline__ void far_headers(uint32_t *__restrict__ far_send, uint32_t world, uint32_t far_next, uint32_t err,
                                             uint32_t n_owned, uint32_t stamp, uint32_t wanted_mig, uint32_t halo_now)
 {
-    const size_t words = WS_HDR_WORDS + (size_t)far_next * 16u;
+    const size_t words = WS_HDR_WORDS + (size_t)far_next * WS_MIG_REC_WORDS;
     for (uint32_t r = 0; r < world; r++) {
         uint32_t *hdr = far_send + r * words;
         hdr[0] = 0;
@@ -1534,7 +1542,7 @@ __device__ __forceinline__ void far_headers(uint32_t *__restrict__ far_send, uin
 // out the same on every rank, so they are derived from a number every rank receives).  far_cur = records per message.
 __global__ void k_far_seal(uint32_t world, uint32_t far_cur, uint32_t *__restrict__ far_send, uint32_t *__restrict__ dyn)
 {
-    const size_t words = WS_HDR_WORDS + (size_t)far_cur * 16u;
+    const size_t words = WS_HDR_WORDS + (size_t)far_cur * WS_MIG_REC_WORDS;
     uint32_t most = 0;
     for (uint32_t r = 0; r < world; r++) most = max(most, far_send[r * words]);
     for (uint32_t r = 0; r < world; r++) far_send[r * words + 6] = most;
@@ -1569,7 +1577,7 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
     const uint32_t tid = threadIdx.x;
     const uint32_t step = dyn[DY_STEP];  // (nobody writes it before the last barrier below)
     uint32_t *status = status_ring + (size_t)(step % status_slots) * world * WS_HDR_WORDS;
-    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;  // words per sending rank in the received far buffer
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * WS_MIG_REC_WORDS;  // words per sending rank in the received far buffer
     const bool left = me > 0, right = me + 1 < world;
     if (tid == 0) {
         s_far = 0;
@@ -1577,16 +1585,8 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         s_nsrc = 0;
     }
     __syncthreads();
-    // far arrivals: the records of the far messages the other ranks addressed to this one (the destination test is
-    // always true since the far messages are per destination; it costs nothing and catches a transport that mixes them up)
-    for (uint32_t t = tid; t < world * far_cap; t += WS_FILL_THREADS) {
-        const uint32_t q = t / far_cap, k = t % far_cap;
-        if (q == me) continue;
-        const uint32_t *msg = far_all + (size_t)q * far_words;
-        if (k >= min(msg[0], far_cap)) continue;
-        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k;
-        if (__float_as_uint(rec[3].x) == me) atomicAdd(&s_far, 1u);
-    }
+    // far arrivals: every record of the far messages the other ranks addressed to this one
+    if (tid < world && tid != me) atomicAdd(&s_far, min(far_all[(size_t)tid * far_words], far_cap));
     if (tid < world) {
         const uint32_t *msg = far_all + (size_t)tid * far_words;
         for (uint32_t w = 0; w < WS_HDR_WORDS; w++) status[tid * WS_HDR_WORDS + w] = msg[w];
@@ -1635,8 +1635,7 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         if (q == me) continue;
         const uint32_t *msg = far_all + (size_t)q * far_words;
         if (k >= min(msg[0], far_cap)) continue;
-        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k;
-        if (__float_as_uint(rec[3].x) == me) src[atomicAdd(&s_nsrc, 1u)] = (3u << 30) | t;
+        src[atomicAdd(&s_nsrc, 1u)] = (3u << 30) | t;
     }
     __syncthreads();
     // apply: source k fills target k (any pairing will do).  After a capacity overrun there are more sources than
@@ -1647,10 +1646,11 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
         const uint32_t tag = from >> 30, idx = from & 0x3FFFFFFFu;
         if (tag) {
             const uint32_t *msg = tag == 1u ? recvL : tag == 2u ? recvR : far_all + (size_t)(idx / far_cap) * far_words;
-            const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)(tag == 3u ? idx % far_cap : idx);
-            const float4 q = rec[2];
-            cur.pos[to] = rec[0];
-            cur.vel[to] = rec[1];
+            const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 2 * (size_t)(tag == 3u ? idx % far_cap : idx);
+            const float4 p = rec[0], v = rec[1];
+            const float4 q = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
+            cur.pos[to] = p;
+            cur.vel[to] = v;
             cur.pred[to] = q;
             const uint32_t c = grid_cell(d, q.x, q.y, q.z);
             cid_cur[to] = c;
@@ -1709,7 +1709,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_fill_count(uint32_t world, uint32_
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     const uint32_t step = dyn[DY_STEP];  // (k_fill_finish advances it)
-    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * WS_MIG_REC_WORDS;
     if (t < world) {
         uint32_t *status = status_ring + (size_t)(step % status_slots) * world * WS_HDR_WORDS;
         const uint32_t *msg = far_all + (size_t)t * far_words;
@@ -1717,15 +1717,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_fill_count(uint32_t world, uint32_
         if (msg[3] != step) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);
     }
     if (t == 0 && ((me > 0 && recvL[3] != step) || (me + 1 < world && recvR[3] != step))) atomicOr(&dyn[DY_ERR], WS_DYN_ERR_STAMP);
-    bool hit = false;
-    if (t < world * far_cap) {
-        const uint32_t q = t / far_cap, k = t % far_cap;
-        const uint32_t *msg = far_all + (size_t)q * far_words;
-        if (q != me && k < min(msg[0], far_cap))
-            hit = __float_as_uint((reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k)[3].x) == me;
-    }
-    const unsigned long long m = __ballot(hit);
-    if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&dyn[DY_F_FAR], (uint32_t)__popcll(m));
+    // far arrivals: every record of the far messages the other ranks addressed to this one
+    if (t < world && t != me) atomicAdd(&dyn[DY_F_FAR], min(far_all[(size_t)t * far_words], far_cap));
 }
 
 __global__ void k_fill_plan(uint32_t world, uint32_t me, uint32_t cap, uint32_t *__restrict__ dyn, const uint32_t *__restrict__ recvL,
@@ -1785,11 +1778,10 @@ __global__ void __launch_bounds__(WS_BLOCK) k_fill_lists(WsDev d, uint32_t world
         is_src = t < dyn[DY_F_NR];
         value = (2u << 30) | t;
     } else if ((t -= b_mig) < world * far_cap) {
-        const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+        const uint32_t far_words = WS_HDR_WORDS + far_cap * WS_MIG_REC_WORDS;
         const uint32_t q = t / far_cap, k = t % far_cap;
         const uint32_t *msg = far_all + (size_t)q * far_words;
-        if (q != me && k < min(msg[0], far_cap))
-            is_src = __float_as_uint((reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)k)[3].x) == me;
+        is_src = q != me && k < min(msg[0], far_cap);
         value = (3u << 30) | t;
     }
     const uint32_t at = wave_append(&dyn[DY_F_NTGT], is_tgt);
@@ -1806,15 +1798,16 @@ __global__ void __launch_bounds__(WS_BLOCK) k_fill_apply(WsDev d, const uint32_t
 {
     const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (t >= min(dyn[DY_F_NTGT], dyn[DY_F_NSRC])) return;  // (after a capacity overrun there are more sources: the excess is dropped)
-    const uint32_t far_words = WS_HDR_WORDS + far_cap * 16u;
+    const uint32_t far_words = WS_HDR_WORDS + far_cap * WS_MIG_REC_WORDS;
     const uint32_t to = tgt[t], from = src[t];
     const uint32_t tag = from >> 30, idx = from & 0x3FFFFFFFu;
     if (tag) {
         const uint32_t *msg = tag == 1u ? recvL : tag == 2u ? recvR : far_all + (size_t)(idx / far_cap) * far_words;
-        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 4 * (size_t)(tag == 3u ? idx % far_cap : idx);
-        const float4 q = rec[2];
-        cur.pos[to] = rec[0];
-        cur.vel[to] = rec[1];
+        const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 2 * (size_t)(tag == 3u ? idx % far_cap : idx);
+        const float4 p = rec[0], v = rec[1];
+        const float4 q = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
+        cur.pos[to] = p;
+        cur.vel[to] = v;
         cur.pred[to] = q;
         const uint32_t c = grid_cell(d, q.x, q.y, q.z);
         cid_cur[to] = c;
@@ -1865,8 +1858,8 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
     }
     const uint32_t b_leave = (uint32_t)std::min<uint64_t>(hole_cap, volume);  // (as many can have left as the messages carry)
     const uint32_t b_arr = (uint32_t)std::min<uint64_t>(volume, 0x3FFFFFFFull);
-    hipLaunchKernelGGL(k_fill_count, dim3(cdiv(std::max(world * far_cap, world), WS_BLOCK)), dim3(WS_BLOCK), 0, s, world, me, dyn, recvL,
-                       recvR, far_all, far_cap, status_ring, status_slots);
+    hipLaunchKernelGGL(k_fill_count, dim3(cdiv(world, WS_BLOCK)), dim3(WS_BLOCK), 0, s, world, me, dyn, recvL, recvR, far_all, far_cap,
+                       status_ring, status_slots);
     hipLaunchKernelGGL(k_fill_plan, dim3(1), dim3(1), 0, s, world, me, cap, dyn, recvL, recvR, mig_cap, hole_cap);
     const uint64_t items = 2ull * b_leave + b_arr + 2ull * mig_cap + (uint64_t)world * far_cap;
     hipLaunchKernelGGL(k_fill_lists, dim3((uint32_t)((items + WS_BLOCK - 1) / WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, world, me, dyn, hole,
