@@ -647,6 +647,15 @@ def main():
                                          "denser floor layer than C3: +36 % / +55 % per particle on one GPU) -- not a scaling efficiency")
         if transport is not None:
             out["config"]["transport"] = type(transport).__name__
+        if distributed and "migration_now" in stats:
+            # what rank 0's fixed-size messages carried when the last window ended (records; 32 bytes each for a migrant
+            # and for a halo-A particle, 8 for halo B): sized by every rank alike from the demand of a few steps earlier
+            out["messages_rank0"] = {
+                "migration_records": stats["migration_now"], "migration_MB_per_direction": stats["migration_now"] * 32 / 1e6,
+                "far_records_per_destination": stats["far_now"], "far_MB_per_link": stats["far_now"] * 32 / 1e6,
+                "halo_records": stats["halo_now"], "halo_MB_per_direction": stats["halo_now"] * 40 / 1e6,
+                "peaks_since_load": {k: stats[k] for k in ("migration_peak", "far_peak", "halo_peak")},
+                "note": "sizes in force at the end of the last timed window; DESIGN.md 6"}
         out["stats"] = stats
         if grid is not None:
             out["config"]["grid_cells"] = grid

@@ -62,3 +62,7 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     assert {"same_config_one_gpu", "speedup_vs_one_gpu_same_config", "c3_equivalent_note"} <= set(line)
     assert line["same_config_one_gpu"] is None and line["speedup_vs_one_gpu_same_config"] is None
     assert "north_star" not in line and line["roofline"]["priced_against"].startswith("hbm")
+    # the sizes of rank 0's messages when the last window ended: below the capacities (they follow the fluid), above the floors
+    m = line["messages_rank0"]
+    assert 4096 <= m["migration_records"] < line["stats"]["migration_capacity"] and m["far_records_per_destination"] >= 256
+    assert abs(m["migration_MB_per_direction"] - m["migration_records"] * 32e-6) < 1e-9

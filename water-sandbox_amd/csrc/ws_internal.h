@@ -20,7 +20,7 @@ struct WsMig {
     uint32_t hole_cap;
     uint32_t *sendL, *sendR;  // neighbour migration messages (header + mig_cap records of 64 B)
     uint32_t mig_cap;
-    uint32_t *far;            // the all-gathered message for particles that cross several slabs
+    uint32_t *far;            // the messages (one per destination rank) for particles that cross several slabs
     uint32_t far_cap;
 };
 
@@ -60,7 +60,7 @@ struct WsDev {
     uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
     const WsMig *mig;              // device copy; non-null = the force epilogue also does migration part 1
     uint32_t mig_limit;            // records the NEXT step's migration messages will carry (<= WsMig::mig_cap; 0 = all of it)
-    uint32_t far_limit;            // ... and its all-gathered far message (<= WsMig::far_cap; 0 = all of it)
+    uint32_t far_limit;            // ... and each of its far messages (<= WsMig::far_cap; 0 = all of it)
 };
 
 // words of the device block `dyn` of a slab handle
@@ -72,7 +72,7 @@ enum {
     DY_ERR,          // sticky WS_DYN_ERR_* bits
     DY_LEFT,         // cumulative: particles that left / arrived
     DY_ARRIVED,
-    DY_FAR,          // cumulative: leavers that took the all-gathered route (crossed more than one slab in a step)
+    DY_FAR,          // cumulative: leavers that took the far route (crossed more than one slab in a step)
     DY_STEP,         // steps whose migration has run since the handle was created / reset (k_migrate_fill counts): the
                      // stamp of every message and the slot of the status ring come from here, not from the host, so a
                      // captured graph of the step replays unchanged
@@ -248,15 +248,15 @@ struct WsSlab {
     uint32_t cap = 0;        // owned particles
     uint32_t halo_cap = 0;   // particles of one boundary layer = ghosts per side = records of a halo message
     uint32_t mig_cap = 0;    // records of a neighbour migration message
-    uint32_t far_cap = 0;    // records of the all-gathered message for particles that cross several slabs
+    uint32_t far_cap = 0;    // records of ONE far message (one per destination rank) for particles that cross several slabs
     uint32_t hole_cap = 0;   // leavers per step (all routes)
     uint32_t max_arrivals = 0;
     // Message SIZES follow the fluid (round 4).  The buffers keep their fixed capacities; what travels each step is a
-    // prefix sized from what every rank reported three to four steps ago (header words 4 / 5 of the all-gathered far
+    // prefix sized from what every rank reported three to four steps ago (header words 4 / 5 / 6 of the far
     // message = the status table): the same table on every rank, hence the same size at both ends of every exchange.
     uint32_t mig_limit_cur = 0;       // records of the migration messages exchanged by the step being enqueued
     uint32_t mig_limit_next = 0;      // ... by the next one (the force kernel of this step fills them: WsDev::mig_limit)
-    uint32_t far_limit_cur = 0, far_limit_next = 0, want_far = 0;  // the same for the all-gathered far message
+    uint32_t far_limit_cur = 0, far_limit_next = 0, want_far = 0;  // the same for the far messages
     uint32_t halo_limit = 0, halo_limit_next = 0;  // records of this step's / the next step's halo messages
     uint32_t want_mig = 0, want_halo = 0;   // maxima over all ranks (header words 4 / 5) and over the last eight tables
     uint32_t want_ring[3][8] = {};          // the last eight tables' maxima: migration, halo, far

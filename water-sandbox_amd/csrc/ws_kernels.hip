@@ -1488,7 +1488,7 @@ void wsk_iota(hipStream_t s, uint32_t *p, uint32_t n)
 // ranges, the ghost counts and the migration counts live in a small device block (`dyn`, WsDyn words) and in the
 // headers of fixed-capacity messages; kernels are launched over host-known UPPER BOUNDS and read the real
 // numbers from there.  Every capacity overrun clamps (so nothing is written out of bounds) and sets a sticky bit
-// in dyn[DY_ERR], which travels to every rank with the next step's all-gather and fails ws_step on all of them.
+// in dyn[DY_ERR], which travels to every rank with the next step's far messages and fails ws_step on all of them.
 // ---------------------------------------------------------------------------------
 // Migration, part 1 for particles that no force kernel has seen yet (the first step after the upload; from then on
 // the force kernel's epilogue does this for the particles it moves): take the ones binned into a ghost layer out of
@@ -1557,7 +1557,7 @@ void wsk_far_seal(hipStream_t s, uint32_t world, uint32_t far_cur, uint32_t *far
 // Migration, part 2 (ONE workgroup; a step moves a few thousand particles at most): count the arrivals, fix the new
 // owned count, then close the holes.  The owned range shrinks / grows from n_old to n_new.  Targets = holes below
 // n_new (+ the new slots when growing); sources = arrivals (tagged with their message in the top two bits) +
-// surviving particles above n_new.  Both lists come out equally long.  Also copies the all-gathered message headers
+// surviving particles above n_new.  Both lists come out equally long.  Also copies the received far messages' headers
 // into `status` (one 4-word row per rank: the host reads it two steps later).
 #define WS_FILL_THREADS 1024
 __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint32_t world, uint32_t me, uint32_t cap,

@@ -161,7 +161,7 @@ class TorchDistTransport(_TransportBase):
 
 
 class NativeRcclTransport:
-    """The transport inside the library (csrc/ws_rccl.cpp): RCCL send/recv groups and all-gathers issued by the
+    """The transport inside the library (csrc/ws_rccl.cpp): RCCL send/recv groups, all-to-alls and all-gathers issued by the
     C++ side itself -- no Python in the step.  The host only moves rank 0's 128-byte unique id to every rank."""
 
     def __init__(self, unique_id, rank, world, device):
