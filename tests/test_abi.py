@@ -84,6 +84,32 @@ def test_create_rejects_bad_arguments_without_touching_a_device(ws):
     assert lib.ws_step(None) == 1 and lib.ws_destroy(None) == 0
 
 
+def test_slab_create_wants_a_complete_transport(ws):
+    """A slab with peers needs all three callbacks (include/wsfluid.h, ws_transport): a table without alltoall_dev -- the
+    per-destination far messages and the status words -- is refused before any device is touched; a world of one may
+    leave it out (it makes no transport call at all) and gets as far as the device check."""
+    lib = ws.load_library()
+    T = ws.slab
+    lib.ws_slab_create.argtypes = [C.POINTER(ws.fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                   C.POINTER(ws.fluid.WsDeviceCfg), C.POINTER(T.WsTransport), C.POINTER(C.c_void_p)]
+    noop3 = T.SENDRECV_T(lambda *a: 0)
+    noop = T.ALLGATHER_DEV_T(lambda *a: 0)
+    p = ws.default_params()
+    pos, ids = np.zeros((4, 3), np.float32), np.arange(4, dtype=np.uint32)
+    cfg = ws.fluid.WsDeviceCfg()
+    cfg.device, cfg.rank, cfg.world_size = 0, 0, 2
+    h = C.c_void_p()
+    incomplete = T.WsTransport(None, noop3, noop, T.ALLGATHER_DEV_T())
+    assert lib.ws_slab_create(C.byref(p), pos.ctypes.data, ids.ctypes.data, 4, 8, C.byref(cfg), C.byref(incomplete), C.byref(h)) == 1
+    assert b"alltoall_dev" in lib.ws_last_error(None) and not h
+    cfg.world_size = 1
+    st = lib.ws_slab_create(C.byref(p), pos.ctypes.data, ids.ctypes.data, 4, 4, C.byref(cfg), C.byref(incomplete), C.byref(h))
+    assert st in (0, 2)  # created (GPU box) or WS_ERR_NO_DEVICE (here): past the argument checks either way
+    if st == 0:
+        lib.ws_destroy.argtypes = [C.c_void_p]
+        lib.ws_destroy(h)
+
+
 def test_no_cpu_fallback(ws):
     """Without a GPU the product must fail loudly, never fall back to a CPU path."""
     import torch
