@@ -2,10 +2,13 @@
 thread each) exchange halos and migrants through the loopback transport.  Because the in-cell order
 is canonical (by particle id) and every slab uses the global y/z cell layout, the merged result must
 equal the single-handle run BIT FOR BIT -- including after particles have migrated between slabs."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _single(ws, pos, params, steps, ieee=False):
@@ -151,6 +154,24 @@ def test_native_rccl_transport_single_rank(ws):
     got[got_ids] = rec
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_native_rccl_collectives_execute_on_a_communicator_of_one():
+    """A slab step with one rank makes no transport call, so the test above never reaches librccl's collectives.  Here
+    the transport's entry points are called directly on a one-rank communicator of the REAL librccl: ncclAllToAll (RCCL's
+    own symbol, bound by name at run time) and ncclAllGather run and deliver -- in a process of its own that loads the
+    library first and never imports torch, so that it runs on the system's HIP runtime and librccl as a C++ host's would
+    (torch bundles its own copies under the same sonames: whichever is loaded first serves the whole process), once with
+    the transport as the process's very first HIP user.  What a one-GPU box can say about the binding; with peers:
+    tests/test_gpu_fake_rccl.py (stand-in) and tests/test_gpu_rccl_two_gpus.py (needs two GPUs)."""
+    import subprocess
+    import sys
+
+    for extra in ([], ["rccl_first"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_one_rank_probe_notorch.py"), "1"] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert "alltoall rc 0 equal True" in out.stdout and "allgather rc 0 equal True" in out.stdout, out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("what", ["ghost_capacity", "capacity"])

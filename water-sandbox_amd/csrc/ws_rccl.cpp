@@ -169,7 +169,17 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
 {
     if (!unique_id || !out || world_size == 0 || rank >= world_size) return WS_ERR_INVALID_ARG;
     if (!load_rccl()) return WS_ERR_COMM;
-    if (hipSetDevice(device) != hipSuccess) return WS_ERR_NO_DEVICE;
+    {
+        // (this may be the process's first HIP call, right after ncclGetUniqueId: say what HIP says if it refuses)
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e == hipSuccess && device >= 0 && device < ndev) e = hipSetDevice(device);
+        else if (e == hipSuccess) e = hipErrorInvalidDevice;
+        if (e != hipSuccess) {
+            g_api.error = std::string("hipSetDevice(") + std::to_string(device) + ") of " + std::to_string(ndev) + " devices: " + hipGetErrorString(e);
+            return WS_ERR_NO_DEVICE;
+        }
+    }
     RcclTransport *t = new RcclTransport();
     t->rank = (int)rank;
     t->world = (int)world_size;
