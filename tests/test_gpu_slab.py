@@ -40,12 +40,12 @@ def test_slabs_reproduce_single_gpu_bitwise(ws, world):
 def test_particles_that_cross_several_slabs_in_one_step_take_the_far_route(ws):
     """Eight thin slabs (8-9 cell layers = ~2.1 units each) and a gravity of 3000 along +x: from the third step on the
     fluid moves more than a slab's width per step (0.83, 1.67, 2.5, 3.3 units), so leavers skip their neighbour and
-    travel in the all-gathered "far" message.  The merged result still equals the single handle bit for bit, and the
-    counters show the route was used.  (Four steps: in the fifth the whole fluid comes back off the far wall at once,
-    more than a 1024-record far message holds -- the overrun case has its own test.)"""
+    travel in the "far" message addressed to their destination rank (one per destination, exchanged all-to-all).  In
+    the fifth step the whole fluid comes back off the far wall at once and keeps sloshing across several slabs per step.
+    The merged result still equals the single handle bit for bit, and the counters show the route was used."""
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(3000.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(4096, 77, list(params.ext_min), list(params.ext_max))
-    steps, world = 4, 8
+    steps, world = 12, 8
     want = _single(ws, pos, params, steps)
     counters = {}
     got, owned = ws.slab.run_loopback(pos, params, world, steps, counters=counters)
@@ -53,7 +53,7 @@ def test_particles_that_cross_several_slabs_in_one_step_take_the_far_route(ws):
     far = sum(c["far"] for c in counters.values())
     left = sum(c["left"] for c in counters.values())
     arrived = sum(c["arrived"] for c in counters.values())
-    assert far > 100, "the far route was not exercised: %r" % (counters,)
+    assert far > 1000, "the far route was not exercised: %r" % (counters,)
     assert left == arrived and left > 0, counters
     assert [counters[r]["owned"] for r in range(world)] == owned
     for f in want.dtype.names:
