@@ -120,6 +120,15 @@ typedef struct ws_device_cfg {
  * synchronise the stream inside its callbacks, so such handles keep launching directly.  Ignores WS_FLAG_PROFILE.  Off by default: direct launches already pipeline on the
  * stream and measure as fast on one MI355X. */
 #define WS_FLAG_GRAPH 8u
+/* Slab handles: every message of a step carries exactly what its sender has for it, instead of a size every rank derives
+ * from the demand of a few steps earlier.  The default never waits for the device but FAILS the run (on every rank, cleanly)
+ * when a message's demand outgrows that size within four steps -- a shock front reaching a slab face broadside does that:
+ * the number of particles changing owner can grow tenfold in one step.  With this flag nothing can overrun below the
+ * buffers' capacities and the messages are as small as they can be (about a quarter of the default's in a steady flow);
+ * the price: ws_step waits for the device twice per step (for four words per rank: before the migration -- the GPU idles for
+ * one small all-gather and a copy -- and before the halos, behind the kernel that needs no ghosts), and the step cannot be
+ * captured (WS_FLAG_GRAPH is ignored).  Every rank must choose alike. */
+#define WS_FLAG_EXACT_MESSAGES 16u
 
 typedef struct ws_handle ws_handle;
 

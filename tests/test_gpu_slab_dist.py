@@ -65,4 +65,5 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     # the sizes of rank 0's messages when the last window ended: below the capacities (they follow the fluid), above the floors
     m = line["messages_rank0"]
     assert 4096 <= m["migration_records"] < line["stats"]["migration_capacity"] and m["far_records_per_destination"] >= 256
+    assert m["sizing"].startswith("from the demand")
     assert abs(m["migration_MB_per_direction"] - m["migration_records"] * 32e-6) < 1e-9

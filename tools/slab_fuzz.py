@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Developer (round 4): randomised slab-identity runs -- a random container, gravity, particle count, slab count and run
+length per case, `world` loopback slabs on this one GPU against the single handle, bit for bit; the counters say which
+routes were used.  usage: slab_fuzz.py [cases] [seed] [exact]   (exact: WS_FLAG_EXACT_MESSAGES)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+import water_sandbox_amd as ws
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
+exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
+bad = over = 0
+for k in range(cases):
+    world = int(rng.integers(2, 9))
+    size = (float(rng.choice([8.0, 16.0, 24.0, 40.0])), float(rng.choice([5.0, 9.0, 12.0])), float(rng.choice([5.0, 9.0])))
+    g = float(rng.choice([0.0, 6.0, 60.0, 600.0, 3000.0])) * float(rng.choice([-1.0, 1.0]))
+    n = int(rng.choice([3000, 20000, 65536, 150000, 600000]))
+    steps = int(rng.integers(8, 70))
+    if int(size[0] / 0.25) + 4 < 3 * world:  # every slab needs a few layers
+        world = 2
+    params = ws.make_params(container_size=size, gravity=(g, -9.8, float(rng.choice([0.0, 40.0])), 0.0))
+    pos = ws.workloads.uniform_cloud(n, int(rng.integers(1, 1 << 30)), list(params.ext_min), list(params.ext_max))
+    w = ws.FluidWorker(pos, params)
+    w.run(steps)
+    want = w.read_vec("particles")
+    w.close()
+    counters = {}
+    row = {"case": k, "world": world, "container": size, "gravity_x": g, "particles": n, "steps": steps}
+    try:
+        got, owned = ws.slab.run_loopback(pos, params, world, steps, counters=counters, exact_messages=exact)
+        same = all(np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)) for f in want.dtype.names)
+        row.update(identical=bool(same), owned_sum_ok=sum(owned) == n, left=sum(c["left"] for c in counters.values()),
+                   far=sum(c["far"] for c in counters.values()),
+                   peaks=[max(c[k] for c in counters.values()) for k in ("migration_peak", "far_peak", "halo_peak")])
+        bad += 0 if (same and sum(owned) == n) else 1
+    except (ws.WsError, RuntimeError) as e:
+        row.update(error=str(e)[:300])
+        # with exact sizes an overrun can only be one of a buffer's CAPACITY (a third of all particles in one cell layer
+        # against a wall ...): reported, not counted as a failure of the sizing
+        if exact and "status 3" in str(e):
+            over += 1
+        else:
+            bad += 1
+    print(json.dumps(row), flush=True)
+print(json.dumps({"cases": cases, "bad": bad, "capacity_overruns": over}), flush=True)
+sys.exit(1 if bad else 0)

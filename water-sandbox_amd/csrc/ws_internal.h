@@ -261,6 +261,14 @@ struct WsSlab {
     uint32_t want_mig = 0, want_halo = 0;   // maxima over all ranks (header words 4 / 5) and over the last eight tables
     uint32_t want_ring[3][8] = {};          // the last eight tables' maxima: migration, halo, far
     uint64_t arrivals_hist[4] = {0, 0, 0, 0};  // upper bounds of the arrivals of the last four steps (launch bound)
+    uint32_t floor_mig = 4096, floor_far = 256, floor_halo = 8192;  // no message is sized below these (records)
+    // WS_FLAG_EXACT_MESSAGES: every message carries exactly what its sender has for it -- ws_step waits for the counts
+    // (one all-gather of four words per rank before the migration, one before the halos, behind the early K4)
+    bool exact_messages = false;
+    uint32_t *xs_send[2] = {nullptr, nullptr}, *xs_all[2] = {nullptr, nullptr}, *xs_host[2] = {nullptr, nullptr};  // [migration | halo]
+    hipEvent_t ev_sizes[2] = {nullptr, nullptr};
+    uint32_t *far_pack = nullptr;     // the far messages at the stride of what travels
+    uint32_t exact_now[3] = {0, 0, 0};  // the records the last step's migration / halo / far messages carried
     uint32_t limit_hold = 0;          // steps for which the limits stay at the full capacities (after a load / parameter change)
     bool fixed_messages = false;      // WS_SLAB_FIXED_MESSAGES=1: always the full capacities (rounds 1-3)
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
@@ -350,8 +358,10 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
                       uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
-                      uint32_t *sendR, uint32_t *far_send, uint32_t far_next);
+                      uint32_t *sendR, uint32_t *far_send, uint32_t far_next, uint64_t leave_bound);
 void wsk_far_seal(hipStream_t s, uint32_t world, uint32_t far_cur, uint32_t *far_send, uint32_t *dyn);
+void wsk_sizes(hipStream_t s, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *dyn, uint32_t *out);
+void wsk_far_pack(hipStream_t s, uint32_t world, uint32_t far_cap, uint32_t far_n, const uint32_t *src, uint32_t *dst);
 void wsk_halo_pack(hipStream_t s, const WsDev &d, const uint32_t *start, WsSorted srt, uint32_t *dyn, uint32_t rowy,
                    uint32_t halo_cap, uint32_t *sendL, uint32_t *sendR, bool densities);
 void wsk_halo_unpack(hipStream_t s, const WsDev &d, uint32_t *start, WsSorted srt, WsXYZ sxyz, uint32_t *dyn, uint32_t rowy,

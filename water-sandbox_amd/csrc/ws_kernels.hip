@@ -1554,6 +1554,39 @@ void wsk_far_seal(hipStream_t s, uint32_t world, uint32_t far_cur, uint32_t *far
     hipLaunchKernelGGL(k_far_seal, dim3(1), dim3(1), 0, s, world, far_cur, far_send, dyn);
 }
 
+// Exact message sizes (WS_FLAG_EXACT_MESSAGES): what this rank's next messages carry, for the all-gather every rank sizes
+// its transfers from -- {records in message a, in message b, word 6 of c (the largest far message, after k_far_seal),
+// the owned count}.  A count may exceed the capacity (the writers count on); the host clamps.
+__global__ void k_sizes(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, const uint32_t *__restrict__ c,
+                        const uint32_t *__restrict__ dyn, uint32_t *__restrict__ out)
+{
+    out[0] = a ? a[0] : 0u;
+    out[1] = b ? b[0] : 0u;
+    out[2] = c ? c[6] : 0u;
+    out[3] = dyn[DY_N];
+}
+
+void wsk_sizes(hipStream_t s, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *dyn, uint32_t *out)
+{
+    hipLaunchKernelGGL(k_sizes, dim3(1), dim3(1), 0, s, a, b, c, dyn, out);
+}
+
+// The `world` far messages, written at the stride of the full capacity, copied to the stride of the `far_n` records
+// that travel (header + records each): the all-to-all takes equal, contiguous segments.
+__global__ void __launch_bounds__(WS_BLOCK) k_far_pack(uint32_t far_cap, uint32_t far_n, const uint32_t *__restrict__ src,
+                                                       uint32_t *__restrict__ dst)
+{
+    const size_t words_src = WS_HDR_WORDS + (size_t)far_cap * WS_MIG_REC_WORDS, words_dst = WS_HDR_WORDS + (size_t)far_n * WS_MIG_REC_WORDS;
+    const uint32_t t = blockIdx.x * WS_BLOCK + threadIdx.x, r = blockIdx.y;
+    if (t < words_dst / 4u) reinterpret_cast<uint4 *>(dst + r * words_dst)[t] = reinterpret_cast<const uint4 *>(src + r * words_src)[t];
+}
+
+void wsk_far_pack(hipStream_t s, uint32_t world, uint32_t far_cap, uint32_t far_n, const uint32_t *src, uint32_t *dst)
+{
+    const uint32_t quads = (WS_HDR_WORDS + far_n * WS_MIG_REC_WORDS) / 4u;
+    hipLaunchKernelGGL(k_far_pack, dim3(cdiv(quads, WS_BLOCK), world), dim3(WS_BLOCK), 0, s, far_cap, far_n, src, dst);
+}
+
 // Migration, part 2 (ONE workgroup; a step moves a few thousand particles at most): count the arrivals, fix the new
 // owned count, then close the holes.  The owned range shrinks / grows from n_old to n_new.  Targets = holes below
 // n_new (+ the new slots when growing); sources = arrivals (tagged with their message in the top two bits) +
@@ -1845,10 +1878,11 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
                       const uint32_t *hole, const uint32_t *recvL, const uint32_t *recvR, uint32_t mig_cap,
                       const uint32_t *far_all, uint32_t far_cap, uint32_t *tgt, uint32_t *src, WsSoA cur, uint32_t *cid_cur,
                       uint32_t *count, uint32_t *status_ring, uint32_t status_slots, uint32_t hole_cap, uint32_t *sendL,
-                      uint32_t *sendR, uint32_t *far_send, uint32_t far_next)
+                      uint32_t *sendR, uint32_t *far_send, uint32_t far_next, uint64_t leave_bound)
 {
-    // (mig_cap / far_cap: the records this step's messages carry -- the host's current limits, not the buffers' capacities;
-    // far_next: the records each far message of the NEXT exchange will carry, the stride the new headers are written at)
+    // (mig_cap / far_cap: the records the RECEIVED messages carry -- the host's current limits, not the buffers' capacities;
+    // far_next: the records each far message of the NEXT exchange will carry, the stride the new headers are written at;
+    // leave_bound: how many particles can have left -- what the messages this rank SENT carry; 0 = as many as it received)
     const uint64_t volume = 2ull * mig_cap + (uint64_t)world * far_cap;
     if (volume <= 49152ull) {
         hipLaunchKernelGGL(k_migrate_fill, dim3(1), dim3(WS_FILL_THREADS), 0, s, d, world, me, cap, dyn, hole, recvL, recvR,
@@ -1856,7 +1890,7 @@ void wsk_migrate_fill(hipStream_t s, const WsDev &d, uint32_t world, uint32_t me
                            sendR, far_send, far_next);
         return;
     }
-    const uint32_t b_leave = (uint32_t)std::min<uint64_t>(hole_cap, volume);  // (as many can have left as the messages carry)
+    const uint32_t b_leave = (uint32_t)std::min<uint64_t>(hole_cap, leave_bound ? leave_bound : volume);
     const uint32_t b_arr = (uint32_t)std::min<uint64_t>(volume, 0x3FFFFFFFull);
     hipLaunchKernelGGL(k_fill_count, dim3(cdiv(world, WS_BLOCK)), dim3(WS_BLOCK), 0, s, world, me, dyn, recvL, recvR, far_all, far_cap,
                        status_ring, status_slots);
