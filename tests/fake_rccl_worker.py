@@ -24,7 +24,7 @@ def calls():
     return [int(x) for x in out]
 
 
-def run_world(pos, params, world, program, graph):
+def run_world(pos, params, world, program, graph, exact=False):
     n = pos.shape[0]
     owner = ws.slab.assign(params, pos, world)
     uid = ws.slab.NativeRcclTransport.unique_id()
@@ -38,7 +38,7 @@ def run_world(pos, params, world, program, graph):
         try:
             tr = ws.slab.NativeRcclTransport(uid, r, world, 0)  # (ncclCommInitRank + ncclCommSplit: rendezvous of all ranks)
             sel = np.flatnonzero(owner == r).astype(np.uint32)
-            w = ws.slab.SlabWorker(pos[sel], sel, n, params, r, world, tr, graph=graph)
+            w = ws.slab.SlabWorker(pos[sel], sel, n, params, r, world, tr, graph=graph, exact_messages=exact)
             created.wait()
             results[r] = (program(w, r), tr.communicators())
             w.close()
@@ -92,19 +92,21 @@ def main():
         own = w.read()[1]                 # (rank-local: the ids this slab owns at the end)
         return rec, mid, w.stats(), w.counters(), own, again, int(fake.fake_rccl_errors())  # (while the communicators live)
 
-    for world, graph in ((2, False), (3, False), (4, False), (2, True), (4, True)):
+    for world, graph, exact in ((2, False, False), (3, False, False), (4, False, False), (2, True, False), (4, True, False), (3, False, True)):
+        # (the last case: WS_FLAG_EXACT_MESSAGES -- the size all-gathers on both communicators, sends and receives of
+        # different sizes in one group, the packed far messages)
         # Captured cases with messages of FIXED size: a change of the message sizes asks for a new capture, and
         # hipGraphInstantiate / hipGraphExecDestroy in the middle of a run wait for the whole device -- including the
         # transport kernels of the other ranks of THIS process, which are waiting for this rank (real ranks are
         # processes).  The direct cases run with the default: sizes that follow the fluid.
         os.environ["WS_SLAB_FIXED_MESSAGES"] = "1" if graph else "0"
         before = calls()
-        res = run_world(pos, params, world, program, graph)
+        res = run_world(pos, params, world, program, graph, exact)
         after = calls()
         err = 0
         for r in res:
             err |= r[0][6]
-        case = {"world": world, "graph": graph, "fake_errors": err,
+        case = {"world": world, "graph": graph, "exact_messages": exact, "fake_errors": err,
                 "communicators": [c for _, c in res],
                 "sendrecv_ops": after[0] - before[0], "allgathers": after[1] - before[1], "new_communicators": after[2] - before[2],
                 "alltoalls": after[3] - before[3],

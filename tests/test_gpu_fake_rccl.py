@@ -28,7 +28,8 @@ def test_rccl_transport_with_peers_direct_and_captured(ws):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["library"] == lib
-    assert [(c["world"], c["graph"]) for c in res["cases"]] == [(2, False), (3, False), (4, False), (2, True), (4, True)]
+    assert [(c["world"], c["graph"], c["exact_messages"]) for c in res["cases"]] == [
+        (2, False, False), (3, False, False), (4, False, False), (2, True, False), (4, True, False), (3, False, True)]
     for c in res["cases"]:
         W = c["world"]
         assert c["fake_errors"] == 0, c                       # (sampled by every rank while its communicators live) no wait timed
@@ -39,6 +40,8 @@ def test_rccl_transport_with_peers_direct_and_captured(ws):
         # per capture, the replays run the recorded kernels)
         # (all-to-all: the far messages and the status words, once per step; all-gather: the collective reads of the program)
         assert c["sendrecv_ops"] > (10 if c["graph"] else 100) and c["alltoalls"] > (3 if c["graph"] else 50) and c["allgathers"] >= 4, c
+        if c["exact_messages"]:
+            assert c["allgathers"] > 100, c                   # two size all-gathers per step
         assert c["migrated"] > 0, c
         assert all(c["mid_frame_positions_identical"]), c
         assert all(c["bit_identical_to_single_handle"]), c

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r04
-timeout -k 10 1000 python3 -m pytest tests/test_gpu_slab_exact.py -x -q -m gpu > gpurun_out/r04/pytest_part.log 2>&1
-echo "exit $?"; tail -25 gpurun_out/r04/pytest_part.log
+timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu > gpurun_out/r04/pytest_gpu.log 2>&1
+echo "exit $?"; tail -6 gpurun_out/r04/pytest_gpu.log
