@@ -101,9 +101,10 @@ def parse_args():
     ap.add_argument("--graph", action="store_true",
                     help="WS_FLAG_GRAPH: replay the step from a captured hipGraph (BASELINE config 5's 'hipGraph-captured step'); "
                          "per-kernel events are not part of a captured step, so the roofline objects are omitted")
-    ap.add_argument("--exact-messages", action="store_true",
-                    help="N > 1: WS_FLAG_EXACT_MESSAGES -- every slab message at exactly its sender's count (ws_step waits for the "
-                         "counts twice per step) instead of sizes derived from the demand of a few steps earlier")
+    ap.add_argument("--lagged-messages", action="store_true",
+                    help="N > 1: WS_FLAG_LAGGED_MESSAGES -- slab message sizes derived from the demand of a few steps earlier (ws_step "
+                         "never waits for the device; a shock front across a slab face fails the run) instead of the default: every "
+                         "message at exactly its sender's count, two short host waits per step.  Implied by --graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settled", action="store_true", help="skip the settled-state window (steps 400..500)")
     ap.add_argument("--no-readback", action="store_true",
@@ -366,7 +367,7 @@ def main():
             return ws.slab.SlabWorker(pos, ids, n_global, params, rank, world, transport, device=local_rank,
                                       stream=None if which == "rccl" else torch.cuda.current_stream().cuda_stream,
                                       profile=profile and not args.graph, ieee_division=ieee, graph=args.graph,
-                                      exact_messages=args.exact_messages)
+                                      lagged_messages=args.lagged_messages)
     else:
         cfg_name, block, size = dist_geometry(args, 1)
         base_name = cfg_name.split("x")[0]
@@ -659,7 +660,7 @@ def main():
                 "far_records_per_destination": stats["far_now"], "far_MB_per_link": stats["far_now"] * 32 / 1e6,
                 "halo_records": stats["halo_now"], "halo_MB_per_direction": stats["halo_now"] * 40 / 1e6,
                 "peaks_since_load": {k: stats[k] for k in ("migration_peak", "far_peak", "halo_peak")},
-                "sizing": "exact (WS_FLAG_EXACT_MESSAGES)" if args.exact_messages else "from the demand of a few steps earlier",
+                "sizing": "from the demand of a few steps earlier (WS_FLAG_LAGGED_MESSAGES)" if (args.lagged_messages or args.graph) else "exact: every message at its sender's count (default)",
                 "note": "sizes in force at the end of the last timed window; DESIGN.md 6"}
         out["stats"] = stats
         if grid is not None:

@@ -120,15 +120,21 @@ typedef struct ws_device_cfg {
  * synchronise the stream inside its callbacks, so such handles keep launching directly.  Ignores WS_FLAG_PROFILE.  Off by default: direct launches already pipeline on the
  * stream and measure as fast on one MI355X. */
 #define WS_FLAG_GRAPH 8u
-/* Slab handles: every message of a step carries exactly what its sender has for it, instead of a size every rank derives
- * from the demand of a few steps earlier.  The default never waits for the device but FAILS the run (on every rank, cleanly)
- * when a message's demand outgrows that size within four steps -- a shock front reaching a slab face broadside does that:
- * the number of particles changing owner can grow tenfold in one step.  With this flag nothing can overrun below the
- * buffers' capacities and the messages are as small as they can be (about a quarter of the default's in a steady flow);
- * the price: ws_step waits for the device twice per step (for four words per rank: before the migration -- the GPU idles for
- * one small all-gather and a copy -- and before the halos, behind the kernel that needs no ghosts), and the step cannot be
- * captured (WS_FLAG_GRAPH is ignored).  Every rank must choose alike. */
+/* Slab handles, how the messages of a step are sized.
+ * DEFAULT (neither flag, no WS_FLAG_GRAPH): every message carries exactly what its sender has for it.  ws_step gathers
+ * four words per rank and waits for them twice per step -- before the migration (the GPU idles for one small all-gather
+ * and a copy) and before the halos (behind the kernel that needs no ghosts).  Nothing can overrun below the buffers'
+ * capacities, and the messages are as small as they can be.
+ * WS_FLAG_LAGGED_MESSAGES (implied by WS_FLAG_GRAPH: a captured step has its sizes baked in): ws_step never waits for
+ * the device; every rank derives the sizes from the demand all ranks reported a few steps earlier (x 4 headroom on the
+ * largest of the last eight reports).  A demand that outgrows that within four steps FAILS the run -- on every rank at the
+ * same step, cleanly, but it fails: a pressure front that crosses a slab face broadside multiplies the particles changing
+ * owner tenfold in one step.  For flows known to be smooth across the slab faces -- the benchmark
+ * trajectories are -- and for captured graphs.
+ * WS_FLAG_EXACT_MESSAGES asks for the default explicitly (and wins over WS_FLAG_GRAPH, which is then ignored).
+ * Every rank must choose alike. */
 #define WS_FLAG_EXACT_MESSAGES 16u
+#define WS_FLAG_LAGGED_MESSAGES 32u
 
 typedef struct ws_handle ws_handle;
 
@@ -247,10 +253,13 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  *   neighbour, plus one all-to-all for the particles that cross several slabs in a step and for the status words) -> sort own
  *   particles -> send the two boundary layers' records to the neighbours (halo A) -> K4 -> send their densities
  *   (halo B) -> K5+K6; with the halos on a second stream while the particles that need no ghosts compute.
- * ws_step never waits for the step it enqueues on a slab handle either (the one thing it may wait for is the status
- * table of the step enqueued two calls earlier -- a bounded run-ahead): every message has a fixed capacity known to both ends
- * (ghost_capacity and sizes derived from it) and carries its record count in a header; the owned count, the layer
- * ranges and the ghost counts stay on the device, kernels are launched over host-side upper bounds.  A capacity
+ * ws_step never waits for the END of the step it enqueues on a slab handle either: every message has a fixed capacity known
+ * to both ends (ghost_capacity and sizes derived from it) and carries its record count in a header; the owned count, the
+ * layer ranges and the ghost counts stay on the device.  By default it waits, twice per step, for four words per rank --
+ * the record counts its messages are sized from (WS_FLAG_EXACT_MESSAGES, above); the rest of the step -- the late
+ * kernels, the second halo, the force kernel -- is still running when it returns.  With WS_FLAG_LAGGED_MESSAGES it
+ * waits for nothing of the step at all (only, a bounded run-ahead, for the status table of the step enqueued two
+ * calls earlier) and launches its kernels over host-side upper bounds.  A capacity
  * overrun clamps, sets a sticky error bit that reaches every rank with the next step's all-to-all, and makes ws_step
  * return WS_ERR_OUT_OF_MEMORY on ALL ranks at the same step (two steps later), before any collective of that step --
  * no rank is left waiting in one.  ws_sync / ws_slab_read_particles / ws_slab_counters report the bits too, as soon

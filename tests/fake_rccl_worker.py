@@ -38,7 +38,7 @@ def run_world(pos, params, world, program, graph, exact=False):
         try:
             tr = ws.slab.NativeRcclTransport(uid, r, world, 0)  # (ncclCommInitRank + ncclCommSplit: rendezvous of all ranks)
             sel = np.flatnonzero(owner == r).astype(np.uint32)
-            w = ws.slab.SlabWorker(pos[sel], sel, n, params, r, world, tr, graph=graph, exact_messages=exact)
+            w = ws.slab.SlabWorker(pos[sel], sel, n, params, r, world, tr, graph=graph, exact_messages=exact, lagged_messages=not exact)
             created.wait()
             results[r] = (program(w, r), tr.communicators())
             w.close()

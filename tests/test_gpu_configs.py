@@ -154,7 +154,8 @@ def test_c5_in_eight_slabs_matches_the_single_handle(ws, steps):
     assert res[0][0] is True and res[7][0] is True
 
 
-def test_c4_in_four_slabs_into_the_rebound_matches_the_single_handle(ws):
+@pytest.mark.parametrize("lagged", [False, True])
+def test_c4_in_four_slabs_into_the_rebound_matches_the_single_handle(ws, lagged):
     """BASELINE.json config 4 in its four slabs, stepped INTO the rebound of the collapsed cloud (200 steps): by then more
     than 300 000 particles leave a slab towards one neighbour per step and more than 100 000 cross several slabs at once
     (the far route), the migration fill runs as its multi-kernel form, and the messages have grown with the fluid from a
@@ -173,7 +174,8 @@ def test_c4_in_four_slabs_into_the_rebound_matches_the_single_handle(ws):
         st = s.stats()
         return None if got is None else bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))), s.num_owned(), st
 
-    res = ws.slab.run_loopback_program(pos, params, 4, program)
+    # (lagged: WS_FLAG_LAGGED_MESSAGES, the sizes bench.py --lagged-messages / --graph run with; default: exact sizes)
+    res = ws.slab.run_loopback_program(pos, params, 4, program, lagged_messages=lagged)
     assert sum(r[1] for r in res) == pos.shape[0]
     assert res[0][0] is True and res[3][0] is True
     assert max(r[2]["migration_peak"] for r in res) > 100000 and max(r[2]["far_peak"] for r in res) > 10000, [r[2] for r in res]

@@ -227,7 +227,7 @@ def test_slab_step_only_enqueues(ws):
 
 @pytest.mark.parametrize("fixed", ["0", "1"])
 def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
-    """The buffers of a slab's messages have fixed capacities (sized for the violent phase of a collapsing cloud); what
+    """WS_FLAG_LAGGED_MESSAGES.  The buffers of a slab's messages have fixed capacities (sized for the violent phase of a collapsing cloud); what
     TRAVELS per step is a prefix sized from what every rank reported a few steps ago -- the same all-gathered table on
     every rank, hence the same size at both ends of every exchange.  WS_SLAB_FIXED_MESSAGES=1 keeps the capacities.
     Either way the result is the single handle's, bit for bit."""
@@ -241,7 +241,7 @@ def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
         s.run(steps)
         return s.read_vec("particles"), s.stats()
 
-    res = ws.slab.run_loopback_program(pos, params, world, program)
+    res = ws.slab.run_loopback_program(pos, params, world, program, lagged_messages=True)
     for rec, st in res:
         for f in want.dtype.names:
             assert np.array_equal(rec[f].view(np.uint32), want[f].view(np.uint32)), f
@@ -257,8 +257,8 @@ def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
 
 def test_four_slabs_through_the_collapse_and_rebound_of_c2_match_the_single_handle(ws):
     """The benchmark trajectory, not a few quiet steps: C2 (262 144 particles) in four slabs through the collapse of the
-    cloud and its rebound (220 steps) -- migration by the ten thousand per step, the multi-kernel migration fill, message
-    sizes that follow the fluid up and down -- is the single handle's result bit for bit, with the DEFAULT capacities
+    cloud and its rebound (220 steps) -- migration by the ten thousand per step, the multi-kernel migration fill, the LAGGED
+    message sizes following the fluid up and down (WS_FLAG_LAGGED_MESSAGES; exact sizes: tests/test_gpu_slab_exact.py) -- is the single handle's result bit for bit, with the DEFAULT capacities
     (rounds 1-3 never stepped a multi-slab run this far: every multi-GPU benchmark configuration overran there)."""
     pos, params = ws.workloads.make_workload("c2", "cloud")
     steps, world = 220, 4
@@ -271,7 +271,7 @@ def test_four_slabs_through_the_collapse_and_rebound_of_c2_match_the_single_hand
             sizes.append(s.stats()["migration_now"])
         return s.read_vec("particles"), s.stats(), sizes, s.counters()
 
-    res = ws.slab.run_loopback_program(pos, params, world, program)
+    res = ws.slab.run_loopback_program(pos, params, world, program, lagged_messages=True)
     for rec, st, sizes, c in res:
         for f in want.dtype.names:
             assert np.array_equal(rec[f].view(np.uint32), want[f].view(np.uint32)), f

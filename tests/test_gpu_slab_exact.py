@@ -1,4 +1,4 @@
-"""WS_FLAG_EXACT_MESSAGES: every message of a slab step at exactly its sender's count (ws_step waits for four words per rank
+"""Exact message sizes (the default of a slab handle; WS_FLAG_EXACT_MESSAGES asks for them explicitly): every message of a slab step at exactly its sender's count (ws_step waits for four words per rank
 twice per step) instead of a size derived from the demand of a few steps earlier.  The lagged sizes never wait but FAIL the
 run when a demand outgrows them within four steps -- a shock front reaching a slab face broadside makes the number of
 particles that change owner grow tenfold in one step (tools/slab_series.py); nothing below the buffers' capacities can
@@ -38,13 +38,13 @@ def test_exact_messages_reproduce_the_single_handle_bitwise(ws, world):
 
 def test_a_shock_front_that_overruns_the_lagged_sizes_passes_with_exact_ones(ws):
     """A dense cloud in a short box with a gravity of 60 along x (case 41 of tools/slab_fuzz.py 100 7): the leavers of one
-    slab face go 8 905, 17 764, 35 103, 162 450 in consecutive steps.  The default sizing -- four times the largest
+    slab face go 8 905, 17 764, 35 103, 162 450 in consecutive steps.  The lagged sizing -- four times the largest
     demand of the last eight tables, four steps old -- is overrun and every rank fails at the same step, cleanly; with
     exact sizes the run is the single handle's, bit for bit."""
     params = ws.make_params(container_size=(8.0, 5.0, 9.0), gravity=(60.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(600000, 99, list(params.ext_min), list(params.ext_max))
     world, steps = 4, 30
-    errs = ws.slab.run_loopback(pos, params, world, steps, collect_errors=True)
+    errs = ws.slab.run_loopback(pos, params, world, steps, collect_errors=True, lagged_messages=True)
     assert sorted(errs) == list(range(world)), "the lagged sizes were expected to be overrun on every rank: %r" % (errs,)
     assert len({k for k, _ in errs.values()}) == 1 and all(e.status == 3 for _, e in errs.values()), errs
     want = _single(ws, pos, params, steps)

@@ -308,7 +308,7 @@ class SlabWorker:
     """One x-slab of the domain on one GPU (ws_slab_create / ws_step / ws_slab_read_particles)."""
 
     def __init__(self, positions, ids, n_global, params, rank, world, transport, device=0, stream=None, profile=False,
-                 capacity=0, ghost_capacity=0, ieee_division=False, graph=False, exact_messages=False):
+                 capacity=0, ghost_capacity=0, ieee_division=False, graph=False, exact_messages=False, lagged_messages=False):
         L = self._L = fluid.load_library()
         L.ws_slab_create.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(fluid.WsDeviceCfg), C.POINTER(WsTransport), C.POINTER(C.c_void_p)]
@@ -322,7 +322,8 @@ class SlabWorker:
         cfg = fluid.WsDeviceCfg()
         cfg.device, cfg.rank, cfg.world_size = device, rank, world
         cfg.flags = ((fluid.WS_FLAG_PROFILE if profile else 0) | (fluid.WS_FLAG_IEEE_DIVISION if ieee_division else 0)
-                     | (fluid.WS_FLAG_GRAPH if graph else 0) | (fluid.WS_FLAG_EXACT_MESSAGES if exact_messages else 0))
+                     | (fluid.WS_FLAG_GRAPH if graph else 0) | (fluid.WS_FLAG_EXACT_MESSAGES if exact_messages else 0)
+                     | (fluid.WS_FLAG_LAGGED_MESSAGES if lagged_messages else 0))
         cfg.capacity, cfg.ghost_capacity = capacity, ghost_capacity
         cfg.stream = stream
         self.params = params
@@ -501,7 +502,7 @@ def run_loopback_program(positions, params, world, program, device=0, **kw):
 
 def run_loopback(positions, params, world, steps, device=0, ieee_division=False, capacity=0, ghost_capacity=0,
                  collect_errors=False, counters=None, change_params=None, sync_every_step=False, state=None,
-                 exact_messages=False):
+                 exact_messages=False, lagged_messages=False):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
     particles of all slabs merged into original-id order.  Test helper for one-GPU boxes.
     collect_errors: instead of raising, return {rank: (steps completed, exception)} for the slabs whose ws_step
@@ -525,7 +526,7 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
             sel = np.flatnonzero(owner == r).astype(np.uint32)
             w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device,
                            ieee_division=ieee_division, capacity=capacity, ghost_capacity=ghost_capacity,
-                           exact_messages=exact_messages)
+                           exact_messages=exact_messages, lagged_messages=lagged_messages)
             if state is not None:
                 w.write_particles(state)
             if collect_errors:
