@@ -397,9 +397,10 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * (WS_FLAG_GRAPH); slab handles: out[5] = the most particles one of this slab's boundary layers has held since the last
  * load and out[6] = the halo capacity it must stay under (ws_device_cfg.ghost_capacity), out[7] = the most particles
  * that left towards one neighbour in one step and out[8] = the migration message's capacity, out[9] = the most that crossed
- * more than one slab towards ONE destination rank in one step and out[10] = the capacity of a far message (one per destination); out[11..13] = the records the NEXT step's
- * migration, halo and far messages will carry (sized from what every rank reported a few steps ago; the capacities
- * with WS_SLAB_FIXED_MESSAGES=1); the rest reserved. */
+ * more than one slab towards ONE destination rank in one step and out[10] = the capacity of a far message (one per destination); out[11..13] = the records the migration, halo
+ * and far messages carry: with exact sizes (the default) what the LAST step's carried, with WS_FLAG_LAGGED_MESSAGES what
+ * the NEXT step's will (sized from what every rank reported a few steps ago; the capacities with
+ * WS_SLAB_FIXED_MESSAGES=1); 0 without peers; the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

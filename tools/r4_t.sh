@@ -1,12 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-out=gpurun_out/r04; mkdir -p $out
-timeout -k 10 400 python3 tools/migration_peak.py c4 1 4 450 > $out/migration_peak_c4_exact.log 2>&1; echo "c4 exit $?"
-timeout -k 10 700 python3 tools/migration_peak.py c5 1 8 450 > $out/migration_peak_c5_exact.log 2>&1; echo "c5 exit $?"
-timeout -k 10 400 python3 tools/migration_peak.py c3 2 2 450 > $out/migration_peak_c3x2_exact.log 2>&1; echo "c3x2 exit $?"
+out=gpurun_out/r04p; mkdir -p $out
+WS_BENCH_FORCE_SLAB=1 timeout -k 10 400 python3 bench.py --no-cpu-baseline > $out/bench_c3_cloud_slab_one_rank.json 2> $out/bench_c3_cloud_slab_one_rank.err; echo "one-rank slab exit $?"
+WS_BENCH_BACKEND=gloo timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 20 --warmup 5 --reps 1 > $out/bench_gloo_rehearsal_2ranks.json 2> $out/bench_gloo_rehearsal_2ranks.err; echo "gloo rehearsal exit $?"
+WS_BENCH_BACKEND=gloo timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29572 bench.py --gpus 2 --steps 20 --warmup 5 --reps 1 --lagged-messages > $out/bench_gloo_rehearsal_2ranks_lagged.json 2> $out/bench_gloo_rehearsal_2ranks_lagged.err; echo "gloo rehearsal lagged exit $?"
 python3 - <<'P'
 import json
-for c in ("c4","c5","c3x2"):
-    rows=[json.loads(l) for l in open("gpurun_out/r04/migration_peak_%s_exact.log"%c) if l.startswith("{")]
-    print(c, [("FAILED" in r) for r in rows].count(True), "failed;", [(r["stats"]["migration_now"], r["stats"]["halo_now"], r["stats"]["far_now"]) for r in rows if "stats" in r])
+for f in ("bench_c3_cloud_slab_one_rank","bench_gloo_rehearsal_2ranks","bench_gloo_rehearsal_2ranks_lagged"):
+    d=json.load(open("gpurun_out/r04p/%s.json"%f)); print(f, round(d["ms_per_step"],3), d.get("settled",{}).get("ms_per_step"), d.get("messages_rank0"))
 P

@@ -1226,7 +1226,9 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
         out[11] = h->slab->mig_limit_next;   // what the next step's messages will carry (they follow the fluid)
         out[12] = h->slab->halo_limit_next;
         out[13] = h->slab->far_limit_next;
-        if (h->slab->exact_messages && h->slab->world > 1) {  // ... what the last step's messages carried
+        if (h->slab->world == 1) {
+            out[11] = out[12] = out[13] = 0;  // no peers, no messages
+        } else if (h->slab->exact_messages) {  // ... what the last step's messages carried
             out[11] = h->slab->exact_now[0];
             out[12] = h->slab->exact_now[1];
             out[13] = h->slab->exact_now[2];
