@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer (round 4): randomised slab-identity runs -- a random container, gravity, particle count, slab count and run
 length per case, `world` loopback slabs on this one GPU against the single handle, bit for bit; the counters say which
-routes were used.  usage: slab_fuzz.py [cases] [seed] [exact]   (exact: WS_FLAG_EXACT_MESSAGES)"""
+routes were used.  usage: slab_fuzz.py [cases] [seed] [exact|lagged] [benign]
+(exact: the default sizes; lagged: WS_FLAG_LAGGED_MESSAGES; benign: gravity along x up to 20 and the benchmark clouds' particle density, 50 per unit volume, instead of up to 3 000 and up to 60 times that)"""
 import json
 import os
 import sys
@@ -14,7 +15,8 @@ import water_sandbox_amd as ws
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
-exact = len(sys.argv) > 3 and sys.argv[3] == "exact"
+exact = not (len(sys.argv) > 3 and sys.argv[3] == "lagged")
+benign = len(sys.argv) > 4 and sys.argv[4] == "benign"
 bad = over = 0
 for k in range(cases):
     world = int(rng.integers(2, 9))
@@ -24,6 +26,9 @@ for k in range(cases):
     steps = int(rng.integers(8, 70))
     if int(size[0] / 0.25) + 4 < 3 * world:  # every slab needs a few layers
         world = 2
+    if benign:
+        g = float(rng.choice([0.0, 6.0, 20.0])) * float(rng.choice([-1.0, 1.0]))
+        n = int(50 * size[0] * size[1] * size[2] * float(rng.choice([0.5, 1.0, 2.0])))
     params = ws.make_params(container_size=size, gravity=(g, -9.8, float(rng.choice([0.0, 40.0])), 0.0))
     pos = ws.workloads.uniform_cloud(n, int(rng.integers(1, 1 << 30)), list(params.ext_min), list(params.ext_max))
     w = ws.FluidWorker(pos, params)
@@ -33,7 +38,7 @@ for k in range(cases):
     counters = {}
     row = {"case": k, "world": world, "container": size, "gravity_x": g, "particles": n, "steps": steps}
     try:
-        got, owned = ws.slab.run_loopback(pos, params, world, steps, counters=counters, exact_messages=exact)
+        got, owned = ws.slab.run_loopback(pos, params, world, steps, counters=counters, lagged_messages=not exact)
         same = all(np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)) for f in want.dtype.names)
         row.update(identical=bool(same), owned_sum_ok=sum(owned) == n, left=sum(c["left"] for c in counters.values()),
                    far=sum(c["far"] for c in counters.values()),
