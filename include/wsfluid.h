@@ -400,7 +400,8 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * more than one slab towards ONE destination rank in one step and out[10] = the capacity of a far message (one per destination); out[11..13] = the records the migration, halo
  * and far messages carry: with exact sizes (the default) what the LAST step's carried, with WS_FLAG_LAGGED_MESSAGES what
  * the NEXT step's will (sized from what every rank reported a few steps ago; the capacities with
- * WS_SLAB_FIXED_MESSAGES=1); 0 without peers; the rest reserved. */
+ * WS_SLAB_FIXED_MESSAGES=1); 0 without peers; out[14] = how often ws_step has waited for message sizes so far (two per
+ * step with exact sizes, never with WS_FLAG_LAGGED_MESSAGES); the rest reserved. */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

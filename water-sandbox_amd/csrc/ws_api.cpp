@@ -1226,6 +1226,7 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
         out[11] = h->slab->mig_limit_next;   // what the next step's messages will carry (they follow the fluid)
         out[12] = h->slab->halo_limit_next;
         out[13] = h->slab->far_limit_next;
+        out[14] = h->slab->size_waits;
         if (h->slab->world == 1) {
             out[11] = out[12] = out[13] = 0;  // no peers, no messages
         } else if (h->slab->exact_messages) {  // ... what the last step's messages carried

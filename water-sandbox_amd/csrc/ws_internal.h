@@ -269,6 +269,7 @@ struct WsSlab {
     hipEvent_t ev_sizes[2] = {nullptr, nullptr};
     uint32_t *far_pack = nullptr;     // the far messages at the stride of what travels
     uint32_t exact_now[3] = {0, 0, 0};  // the records the last step's migration / halo / far messages carried
+    uint32_t size_waits = 0;            // host waits for message sizes so far (two per step with exact sizes)
     uint32_t limit_hold = 0;          // steps for which the limits stay at the full capacities (after a load / parameter change)
     bool fixed_messages = false;      // WS_SLAB_FIXED_MESSAGES=1: always the full capacities (rounds 1-3)
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
