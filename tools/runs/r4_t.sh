@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=gpurun_out/r04; mkdir -p $out
-timeout -k 10 1000 python3 -m pytest tests/test_gpu_slab.py tests/test_gpu_slab_exact.py tests/test_gpu_slab_frame.py tests/test_gpu_fake_rccl.py tests/test_gpu_host.py -x -q -m gpu > $out/pytest_part.log 2>&1
-echo "exit $?"; tail -5 $out/pytest_part.log
+timeout -k 10 1000 python3 tools/slab_fuzz.py 1000 12345 exact > $out/slab_fuzz_exact_1000.log 2>&1; echo "exact 1000: exit $? $(tail -1 $out/slab_fuzz_exact_1000.log)"
+grep '"error"\|"identical": false\|owned_sum_ok": false' $out/slab_fuzz_exact_1000.log | cut -c1-330 | head
