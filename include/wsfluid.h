@@ -90,9 +90,9 @@ typedef struct ws_device_cfg {
     uint32_t world_size;     /* number of slabs (0 or 1 = single GPU) */
     uint32_t capacity;       /* slabs: max particles this handle may own (0 = 2 n_local + 2^20);
                                 head-room for particles migrating in */
-    uint32_t ghost_capacity; /* slabs: max particles of ONE boundary layer = ghosts per face = records of a halo
-                                message, a FIXED size both neighbours know (0 = 4 n_global / nx + 2^14, nx = cell
-                                layers along x: four times an evenly spread layer) */
+    uint32_t ghost_capacity; /* slabs: max particles of ONE boundary layer = ghosts per face = the capacity of a halo
+                                message (0 = 16 n_global / nx + 2^15, nx = cell layers along x: sixteen times an evenly
+                                spread layer; what travels per step is sized by the layer's actual population) */
     uint32_t reserved[2];
     void *stream;            /* hipStream_t to enqueue on, or NULL: the library creates its own.
                                 A host that moves halos with its own communication library passes
