@@ -130,7 +130,8 @@ typedef struct ws_device_cfg {
  * largest of the last eight reports).  A demand that outgrows that within four steps FAILS the run -- on every rank at the
  * same step, cleanly, but it fails: a pressure front that crosses a slab face broadside multiplies the particles changing
  * owner tenfold in one step.  For flows known to be smooth across the slab faces -- the benchmark
- * trajectories are -- and for captured graphs.
+ * trajectories are -- and for captured graphs (WS_SLAB_FIXED_MESSAGES=1 in the environment makes such a handle send every
+ * message at its full capacity instead: it cannot overrun either, and moves far more bytes).
  * WS_FLAG_EXACT_MESSAGES asks for the default explicitly (and wins over WS_FLAG_GRAPH, which is then ignored).
  * Every rank must choose alike. */
 #define WS_FLAG_EXACT_MESSAGES 16u
