@@ -1,5 +1,5 @@
 """The library's RCCL transport (csrc/ws_rccl.cpp) with PEERS, on a one-GPU box: a child process in which
-WS_RCCL_LIBRARY points at the tests' stand-in for librccl (tests/fake_rccl/fake_rccl.hip: the ten nccl* symbols, ranks =
+WS_RCCL_LIBRARY points at the tests' stand-in for librccl (tests/fake_rccl/fake_rccl.hip: the eleven nccl* symbols, ranks =
 host threads, stream-ordered device-side handshakes, capturable).  What runs is the product's own transport code --
 ncclCommInitRank, ncclCommSplit, the grouped ncclSend / ncclRecv with `rank - 1` / `rank + 1`, ncclAllGather, one
 communicator per stream -- under the slab step, directly and (WS_GRAPH_MULTIRANK=1) inside captured hipGraphs.
@@ -49,6 +49,21 @@ def test_rccl_transport_with_peers_direct_and_captured(ws):
             assert min(c["graph_steps"]) >= 50, c             # replays of captured steps with transport calls inside
         else:
             assert c["graph_steps"] == [0] * W, c
+
+
+def test_thin_and_thick_slabs_agree_on_the_halo_stream(tmp_path):
+    """tests/fake_rccl_thin_worker.py: eight slabs of two or three cell layers each; the halos must
+    travel on the same communicator on every rank (decided from the thinnest slab of the world -- a rank deciding from its
+    own thickness, as until round 4, would exchange its halos on the other communicator of the RCCL transport)."""
+    lib = os.path.join(ROOT, "tests", "libfakerccl.so")
+    env = dict(os.environ, WS_RCCL_LIBRARY=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="24")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl_thin_worker.py")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["errors"] == [] and res["fake_errors"] == [0] * 8, res
+    assert min(res["owned_layers"]) < 3 <= max(res["owned_layers"]), res  # the scenario: thin slabs beside a thick one
+    assert res["identical"] == [True] * 8 and sum(res["owned"]) == 20000, res
 
 
 def test_the_product_never_defaults_to_the_stand_in():
