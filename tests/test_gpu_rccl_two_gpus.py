@@ -27,6 +27,8 @@ def _gpus():
 def test_two_ranks_through_native_rccl_match_the_single_handle_bitwise(ws, tmp_path, graph):
     steps = 60
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", WS_GRAPH_MULTIRANK="1")
+    if graph == "1":
+        env["WS_SLAB_FIXED_MESSAGES"] = "1"  # (a captured step has its message sizes baked in: no re-captures while they settle)
     pattern = str(tmp_path / "rccl_%d.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29561", os.path.join(ROOT, "tests", "dist_rccl_worker.py"), pattern, str(steps), graph]
