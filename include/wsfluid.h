@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define WS_ABI_VERSION 1
+/* 2 (round 5): ws_transport starts with struct_size and has four callbacks; flags 64 / 128 / 256 have meanings; ws_read_stats out[5..14] are assigned.  A host built against
+ * version 1 must not pass its structs to this library: compare ws_abi_version() with WS_ABI_VERSION at start-up. */
+#define WS_ABI_VERSION 2
 
 typedef enum ws_status {
     WS_OK = 0,
@@ -130,12 +132,25 @@ typedef struct ws_device_cfg {
  * largest of the last eight reports).  A demand that outgrows that within four steps FAILS the run -- on every rank at the
  * same step, cleanly, but it fails: a pressure front that crosses a slab face broadside multiplies the particles changing
  * owner tenfold in one step.  For flows known to be smooth across the slab faces -- the benchmark
- * trajectories are -- and for captured graphs (WS_SLAB_FIXED_MESSAGES=1 in the environment makes such a handle send every
- * message at its full capacity instead: it cannot overrun either, and moves far more bytes).
+ * trajectories are.
+ * WS_FLAG_FIXED_MESSAGES: every message travels at its full CAPACITY.  ws_step never waits, nothing below the
+ * capacities can overrun, the sizes never change (so a captured step is never re-captured) -- and every link moves the
+ * capacity every step (DESIGN.md 6 has the bytes).  This is what WS_FLAG_GRAPH uses on a handle with peers unless
+ * WS_FLAG_LAGGED_MESSAGES is given with it: a captured multi-rank step is safe by default, the bet is the opt-in.
  * WS_FLAG_EXACT_MESSAGES asks for the default explicitly (and wins over WS_FLAG_GRAPH, which is then ignored).
- * Every rank must choose alike. */
+ * Every rank must choose alike: ws_slab_create compares the ranks' choices and fails on ALL of them
+ * (WS_ERR_INVALID_ARG) when they differ. */
 #define WS_FLAG_EXACT_MESSAGES 16u
 #define WS_FLAG_LAGGED_MESSAGES 32u
+#define WS_FLAG_FIXED_MESSAGES 64u
+/* Slab handles: keep the halo exchanges on the step's own stream (no early / late split of K4 / K5, no second
+ * communicator).  Same results; for transports that cannot drive two streams, and for A/B runs.  Every rank alike. */
+#define WS_FLAG_NO_OVERLAP 128u
+/* Slab handles with peers: let WS_FLAG_GRAPH capture the step although no run on two or more GPUs has executed a
+ * captured transport call yet (the path runs through the tests' stand-in for librccl only: DESIGN.md 6).  Needs the
+ * library's own RCCL transport with two communicators.  Without it a multi-rank handle launches directly.  Every rank
+ * alike. */
+#define WS_FLAG_GRAPH_MULTIRANK 256u
 
 typedef struct ws_handle ws_handle;
 
@@ -273,6 +288,9 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in);
  * loopback).  The particle order inside a cell is canonical (by id), so an N-slab run reproduces the single-GPU
  * run bit for bit.  The reference has no multi-device path; this is the scale-out row of SURVEY.md 8(e). */
 typedef struct ws_transport {
+    uint64_t struct_size; /* sizeof(ws_transport) of the host's build: ws_slab_create refuses a table that is shorter
+                             than the one it was compiled with (a version-1 host's three-callback struct) instead of
+                             calling through whatever lies behind it */
     void *ctx;
     /* Stream-ordered exchange of nseg buffers with each x-neighbour, d = 0 (rank - 1) and d = 1 (rank + 1), as
      * ONE group of point-to-point transfers: for segment k send send_bytes[2k + d] bytes from DEVICE pointer

@@ -35,6 +35,14 @@ def refcheck(ws):
     return ws.fluid.bind_library(ws.build.build_refcheck_library())
 
 
+@pytest.fixture(scope="session")
+def devlib(ws):
+    """The TEST-ONLY / developer build of the product sources with -DWS_DEV_HOOKS (tests/libwsfluid_dev.so): the only
+    build that reads environment hooks (WS_VARIANT, WS_CELL_BUDGET, WS_RCCL_LIBRARY ...: csrc/ws_devhooks.h).  The
+    product library reads no environment variable (tests/test_no_experiment_switches.py)."""
+    return ws.fluid.bind_library(ws.build.build_dev_library())
+
+
 def pytest_sessionfinish(session, exitstatus):
     """Tolerance-usage report: every float comparison against the oracle made in this session (case, arithmetic,
     field, L-inf error, noise unit, tolerance, error / tolerance).  Written where gpurun brings it back from the GPU

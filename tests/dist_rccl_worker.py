@@ -25,7 +25,8 @@ def main():
     box = [ws.slab.NativeRcclTransport.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     tr = ws.slab.NativeRcclTransport(box[0], rank, world, dev)
-    w = ws.slab.SlabWorker(pos[sel], sel, pos.shape[0], params, rank, world, tr, device=dev, graph=graph)
+    # graph: WS_FLAG_GRAPH | WS_FLAG_GRAPH_MULTIRANK -- a captured step with peers travels with fixed-capacity messages
+    w = ws.slab.SlabWorker(pos[sel], sel, pos.shape[0], params, rank, world, tr, device=dev, graph=graph, graph_multirank=graph)
     w.run(steps // 2)
     mid = w.read_positions()              # the frame loop's collective read
     w.run(steps - steps // 2)

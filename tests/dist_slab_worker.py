@@ -15,6 +15,7 @@ import water_sandbox_amd as ws  # noqa: E402
 def main():
     out_path = sys.argv[1]
     steps = int(sys.argv[2])
+    overlap = len(sys.argv) < 4 or sys.argv[3] != "0"  # "0": WS_FLAG_NO_OVERLAP
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -25,7 +26,7 @@ def main():
     sel = np.flatnonzero(owner == rank).astype(np.uint32)
     tr = ws.slab.TorchDistTransport(rank, world, 0, data_group=None, ctrl_group=None)
     w = ws.slab.SlabWorker(pos[sel], sel, pos.shape[0], params, rank, world, tr, device=0,
-                           stream=torch.cuda.current_stream().cuda_stream)
+                           stream=torch.cuda.current_stream().cuda_stream, overlap=overlap)
     w.run(steps)
     rec, ids = w.read()
     np.savez(out_path % rank, rec=rec, ids=ids)

@@ -18,6 +18,7 @@ import water_sandbox_amd as ws
 
 fake = C.CDLL(os.environ["WS_RCCL_LIBRARY"])
 fake.fake_rccl_errors.restype = C.c_uint32
+DEV = ws.fluid.bind_library(ws.build.build_dev_library())  # the developer build: the only one that honours WS_RCCL_LIBRARY
 world, steps = 8, 40
 params = ws.make_params(container_size=(4.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
 pos = ws.workloads.uniform_cloud(20000, 4321, list(params.ext_min), list(params.ext_max))
@@ -25,17 +26,17 @@ single = ws.FluidWorker(pos, params)
 single.run(steps)
 want = single.read_vec("particles")
 single.close()
-owner = ws.slab.assign(params, pos, world)
-uid = ws.slab.NativeRcclTransport.unique_id()
+owner = ws.slab.assign(params, pos, world, DEV)
+uid = ws.slab.NativeRcclTransport.unique_id(DEV)
 results, errors = [None] * world, []
 created = threading.Barrier(world, timeout=120)
 
 
 def body(r):
     try:
-        tr = ws.slab.NativeRcclTransport(uid, r, world, 0)
+        tr = ws.slab.NativeRcclTransport(uid, r, world, 0, library=DEV)
         sel = np.flatnonzero(owner == r).astype(np.uint32)
-        w = ws.slab.SlabWorker(pos[sel], sel, pos.shape[0], params, r, world, tr)
+        w = ws.slab.SlabWorker(pos[sel], sel, pos.shape[0], params, r, world, tr, library=DEV)
         created.wait()
         dims = np.zeros(3, np.uint32)
         w._check(w._L.ws_grid_dims(w._h, dims.ctypes.data))

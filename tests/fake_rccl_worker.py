@@ -1,5 +1,6 @@
-"""Child process of tests/test_gpu_fake_rccl.py: WS_RCCL_LIBRARY names the tests' stand-in for librccl (tests/fake_rccl/),
-so ws_rccl_transport_create binds IT -- and the library's RCCL transport (csrc/ws_rccl.cpp: peer arithmetic, segment
+"""Child process of tests/test_gpu_fake_rccl.py: WS_RCCL_LIBRARY names the tests' stand-in for librccl (tests/fake_rccl/)
+and the slab handles are made by the DEVELOPER build of the library (tests/libwsfluid_dev.so: the only build that honours
+that variable), so ws_rccl_transport_create binds IT -- and the library's RCCL transport (csrc/ws_rccl.cpp: peer arithmetic, segment
 order, grouped send / recv, the all-to-all and the all-gather, two communicators bound to two streams, ncclCommSplit) runs with real
 peers: `world` slab handles in this one process, one host thread each, on the one GPU.  Prints one JSON object."""
 import ctypes as C
@@ -16,6 +17,7 @@ import water_sandbox_amd as ws
 
 fake = C.CDLL(os.environ["WS_RCCL_LIBRARY"])
 fake.fake_rccl_errors.restype = C.c_uint32
+DEV = ws.fluid.bind_library(ws.build.build_dev_library())  # same sources as the product + csrc/ws_devhooks.h's hooks
 
 
 def calls():
@@ -26,8 +28,8 @@ def calls():
 
 def run_world(pos, params, world, program, graph, exact=False):
     n = pos.shape[0]
-    owner = ws.slab.assign(params, pos, world)
-    uid = ws.slab.NativeRcclTransport.unique_id()
+    owner = ws.slab.assign(params, pos, world, DEV)
+    uid = ws.slab.NativeRcclTransport.unique_id(DEV)
     results, errors = [None] * world, []
     # Ranks share ONE process here, and HIP refuses a legacy-stream call of one thread while another thread captures a
     # graph; real ranks are processes.  The library itself no longer uses the legacy stream, but creation (allocations)
@@ -36,9 +38,12 @@ def run_world(pos, params, world, program, graph, exact=False):
 
     def body(r):
         try:
-            tr = ws.slab.NativeRcclTransport(uid, r, world, 0)  # (ncclCommInitRank + ncclCommSplit: rendezvous of all ranks)
+            tr = ws.slab.NativeRcclTransport(uid, r, world, 0, library=DEV)  # (ncclCommInitRank + ncclCommSplit: rendezvous of all ranks)
             sel = np.flatnonzero(owner == r).astype(np.uint32)
-            w = ws.slab.SlabWorker(pos[sel], sel, n, params, r, world, tr, graph=graph, exact_messages=exact, lagged_messages=not exact)
+            # a captured step with peers: WS_FLAG_GRAPH | WS_FLAG_GRAPH_MULTIRANK, messages at their FIXED capacities (the
+            # default of a captured multi-rank step); direct cases: lagged or exact sizes
+            w = ws.slab.SlabWorker(pos[sel], sel, n, params, r, world, tr, graph=graph, graph_multirank=graph, exact_messages=exact,
+                                   lagged_messages=not exact and not graph, library=DEV)
             created.wait()
             results[r] = (program(w, r), tr.communicators())
             w.close()
@@ -95,11 +100,10 @@ def main():
     for world, graph, exact in ((2, False, False), (3, False, False), (4, False, False), (2, True, False), (4, True, False), (3, False, True)):
         # (the last case: WS_FLAG_EXACT_MESSAGES -- the size all-gathers on both communicators, sends and receives of
         # different sizes in one group, the packed far messages)
-        # Captured cases with messages of FIXED size: a change of the message sizes asks for a new capture, and
-        # hipGraphInstantiate / hipGraphExecDestroy in the middle of a run wait for the whole device -- including the
-        # transport kernels of the other ranks of THIS process, which are waiting for this rank (real ranks are
-        # processes).  The direct cases run with the default: sizes that follow the fluid.
-        os.environ["WS_SLAB_FIXED_MESSAGES"] = "1" if graph else "0"
+        # Captured cases travel with messages of FIXED size (what WS_FLAG_GRAPH chooses with peers): a change of the
+        # message sizes would ask for a new capture, and hipGraphInstantiate / hipGraphExecDestroy in the middle of a run
+        # wait for the whole device -- including the transport kernels of the other ranks of THIS process, which are
+        # waiting for this rank (real ranks are processes).  The direct cases run with sizes that follow the fluid.
         before = calls()
         res = run_world(pos, params, world, program, graph, exact)
         after = calls()

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(ws):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(ws.fluid.ABI_SYMBOLS) == names  # the Python binding tracks the header
-    assert lib.ws_abi_version() == 1
+    assert lib.ws_abi_version() == 2 == ws.fluid.WS_ABI_VERSION  # round 5: ws_transport.struct_size + four callbacks, new flags
 
 
 def test_struct_layouts_match_the_reference_records(ws):
@@ -99,7 +99,12 @@ def test_slab_create_wants_a_complete_transport(ws):
     cfg = ws.fluid.WsDeviceCfg()
     cfg.device, cfg.rank, cfg.world_size = 0, 0, 2
     h = C.c_void_p()
-    incomplete = T.WsTransport(None, noop3, noop, T.ALLGATHER_DEV_T())
+    incomplete = T.WsTransport(C.sizeof(T.WsTransport), None, noop3, noop, T.ALLGATHER_DEV_T())
+    # a table from a host built against ABI version 1 (three callbacks, no struct_size: whatever lies there is smaller
+    # than this library's struct) is refused before any member behind it is looked at
+    short = T.WsTransport(C.sizeof(T.WsTransport) - 8, None, noop3, noop, noop)
+    assert lib.ws_slab_create(C.byref(p), pos.ctypes.data, ids.ctypes.data, 4, 8, C.byref(cfg), C.byref(short), C.byref(h)) == 1
+    assert b"struct_size" in lib.ws_last_error(None) and not h
     assert lib.ws_slab_create(C.byref(p), pos.ctypes.data, ids.ctypes.data, 4, 8, C.byref(cfg), C.byref(incomplete), C.byref(h)) == 1
     assert b"alltoall_dev" in lib.ws_last_error(None) and not h
     cfg.world_size = 1

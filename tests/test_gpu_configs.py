@@ -115,18 +115,17 @@ def test_full_size_properties_c5(ws):
     _full_size_properties(ws, "c5", 8)
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
-def test_c4_in_four_slabs_matches_the_single_handle(ws, monkeypatch, overlap):
+@pytest.mark.parametrize("overlap", [False, True], ids=["no-overlap", "overlap"])
+def test_c4_in_four_slabs_matches_the_single_handle(ws, overlap):
     """BASELINE.json config 4 in its 4-GPU decomposition (four x-slabs; loopback transport on the one test GPU):
     every field of every particle bit-identical to the single handle, with and without halo / compute overlap."""
-    monkeypatch.setenv("WS_SLAB_OVERLAP", overlap)
     pos, params = ws.workloads.make_workload("c4", "cloud")
     steps = 6
     w = ws.FluidWorker(pos, params)
     w.run(steps)
     want = w.read_vec("particles")
     w.close()
-    got, owned = ws.slab.run_loopback(pos, params, 4, steps)
+    got, owned = ws.slab.run_loopback(pos, params, 4, steps, overlap=overlap)
     assert sum(owned) == pos.shape[0]
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f

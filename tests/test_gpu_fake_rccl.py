@@ -1,8 +1,9 @@
-"""The library's RCCL transport (csrc/ws_rccl.cpp) with PEERS, on a one-GPU box: a child process in which
+"""The library's RCCL transport (csrc/ws_rccl.cpp) with PEERS, on a one-GPU box: a child process that loads the DEVELOPER
+build of the library (tests/libwsfluid_dev.so -- the product library honours no environment variable) and in which
 WS_RCCL_LIBRARY points at the tests' stand-in for librccl (tests/fake_rccl/fake_rccl.hip: the eleven nccl* symbols, ranks =
 host threads, stream-ordered device-side handshakes, capturable).  What runs is the product's own transport code --
 ncclCommInitRank, ncclCommSplit, the grouped ncclSend / ncclRecv with `rank - 1` / `rank + 1`, ncclAllGather, one
-communicator per stream -- under the slab step, directly and (WS_GRAPH_MULTIRANK=1) inside captured hipGraphs.
+communicator per stream -- under the slab step, directly and (WS_FLAG_GRAPH | WS_FLAG_GRAPH_MULTIRANK, fixed-capacity messages) inside captured hipGraphs.
 It does not replace a run on two GPUs: the wire, RCCL's own kernels and its proxy threads are not here."""
 import json
 import os
@@ -17,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_rccl_transport_with_peers_direct_and_captured(ws):
     lib = ws.build.build_fake_rccl()
-    env = dict(os.environ, WS_RCCL_LIBRARY=lib, WS_GRAPH_MULTIRANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+    env = dict(os.environ, WS_RCCL_LIBRARY=lib, HSA_ENABLE_IPC_MODE_LEGACY="0",
                GPU_MAX_HW_QUEUES="24")  # every stream of every rank on a hardware queue of its own: a rank's wait kernel
     #                                     must never sit in front of the kernel it waits for
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl_worker.py")], env=env, capture_output=True,
@@ -67,12 +68,15 @@ def test_thin_and_thick_slabs_agree_on_the_halo_stream(tmp_path):
 
 
 def test_the_product_never_defaults_to_the_stand_in():
-    """WS_RCCL_LIBRARY is an explicit override: no product source names the tests' library (build.py only knows how to
-    compile it for the tests, as it does for the reference-order library)."""
+    """WS_RCCL_LIBRARY is a hook of the DEVELOPER build alone (csrc/ws_devhooks.h): no product source names the tests'
+    library (build.py only knows how to compile it for the tests, as it does for the reference-order library), and the
+    product binary does not even contain the variable's name."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "water-sandbox_amd")):
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".inc", ".h", ".hpp")) and f != "build.py":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "libfakerccl" not in text, os.path.join(dirpath, f)
     rccl = open(os.path.join(ROOT, "water-sandbox_amd", "csrc", "ws_rccl.cpp")).read()
-    assert 'getenv("WS_RCCL_LIBRARY")' in rccl and '"librccl.so.1"' in rccl
+    assert 'WS_DEV_ENV("WS_RCCL_LIBRARY")' in rccl and "getenv" not in rccl and '"librccl.so.1"' in rccl
+    product = open(os.path.join(ROOT, "water-sandbox_amd", "libwsfluid.so"), "rb").read()
+    assert b"WS_RCCL_LIBRARY" not in product and b"libfakerccl" not in product

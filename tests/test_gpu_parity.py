@@ -87,18 +87,19 @@ def test_free_running_matches_first_steps(oracle, ws):
     worker.close()
 
 
-def _run_variant(ws, variant, pos, params, steps, ieee=False):
+def _run_variant(ws, variant, pos, params, steps, ieee=False, devlib=None):
+    """`listed` = the product library as it ships; `simple` = the one-thread-per-particle kernels of the same sources,
+    selected through the developer build's WS_VARIANT hook (the product library has no such switch)."""
     import os
 
-    old = os.environ.get("WS_VARIANT")
-    os.environ["WS_VARIANT"] = variant
-    try:
+    if variant == "listed":
         w = ws.FluidWorker(pos, params, ieee_division=ieee)
-    finally:
-        if old is None:
+    else:
+        os.environ["WS_VARIANT"] = variant
+        try:
+            w = ws.FluidWorker(pos, params, ieee_division=ieee, library=devlib)
+        finally:
             os.environ.pop("WS_VARIANT", None)
-        else:
-            os.environ["WS_VARIANT"] = old
     w.run(steps)
     out = w.read_vec("particles")
     w.close()
@@ -107,13 +108,13 @@ def _run_variant(ws, variant, pos, params, steps, ieee=False):
 
 @BOTH_ARITHMETICS
 @pytest.mark.parametrize("name,dist,steps", [("c2", "cloud", 12), ("c2", "lattice", 6), ("c1", "cloud", 8), ("c2", "cloud", 150)])
-def test_listed_kernels_equal_simple_kernels_bitwise(ws, name, dist, steps, ieee):
+def test_listed_kernels_equal_simple_kernels_bitwise(ws, devlib, name, dist, steps, ieee):
     """The listed density/force kernels (planar radius sweep, LDS compaction, neighbour lists) visit neighbours in
     the same order with the same operations as the one-thread-per-particle kernels: every field must be
     bit-identical, also after many free-running steps (any divergence would be amplified, not hidden) -- with
     either arithmetic."""
     pos, params = ws.workloads.make_workload(name, dist)
-    a = _run_variant(ws, "simple", pos, params, steps, ieee)
+    a = _run_variant(ws, "simple", pos, params, steps, ieee, devlib)
     b = _run_variant(ws, "listed", pos, params, steps, ieee)
     for f in a.dtype.names:
         assert np.array_equal(a[f].view(np.uint32), b[f].view(np.uint32)), f

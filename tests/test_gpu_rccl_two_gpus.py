@@ -1,5 +1,5 @@
-"""The library's RCCL transport with the real librccl between two GPUs: direct launches and (WS_GRAPH_MULTIRANK=1)
-captured hipGraphs against the single handle, bit for bit.  SKIPPED on a one-GPU box -- this pool's; there the same
+"""The library's RCCL transport with the real librccl between two GPUs: direct launches and (WS_FLAG_GRAPH | WS_FLAG_GRAPH_MULTIRANK:
+fixed-capacity messages) captured hipGraphs against the single handle, bit for bit.  SKIPPED on a one-GPU box -- this pool's; there the same
 transport code runs with peers through the tests' stand-in for librccl (tests/test_gpu_fake_rccl.py).  No multi-GPU run
 of this library has happened yet: this is the first thing to run on a node that has two."""
 import os
@@ -26,9 +26,7 @@ def _gpus():
 @pytest.mark.parametrize("graph", ["0", "1"])
 def test_two_ranks_through_native_rccl_match_the_single_handle_bitwise(ws, tmp_path, graph):
     steps = 60
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", WS_GRAPH_MULTIRANK="1")
-    if graph == "1":
-        env["WS_SLAB_FIXED_MESSAGES"] = "1"  # (a captured step has its message sizes baked in: no re-captures while they settle)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     pattern = str(tmp_path / "rccl_%d.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29561", os.path.join(ROOT, "tests", "dist_rccl_worker.py"), pattern, str(steps), graph]

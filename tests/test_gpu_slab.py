@@ -114,25 +114,23 @@ def test_slabs_reproduce_single_gpu_bitwise_with_ieee_division(ws):
 
 
 @pytest.mark.parametrize("world", [2, 3, 4])
-def test_slabs_with_halo_overlap_give_the_same_bits(ws, monkeypatch, world):
-    """WS_SLAB_OVERLAP=1: halos on a second stream, K4 / K5 split into an early range and the late boundary layers."""
-    monkeypatch.setenv("WS_SLAB_OVERLAP", "1")
+def test_slabs_with_halo_overlap_give_the_same_bits(ws, world):
+    """The default: halos on a second stream, K4 / K5 split into an early range and the late boundary layers."""
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
     want = _single(ws, pos, params, 40)
-    got, owned = ws.slab.run_loopback(pos, params, world, 40)
+    got, owned = ws.slab.run_loopback(pos, params, world, 40, overlap=True)
     assert sum(owned) == pos.shape[0]
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
 
-def test_slabs_without_halo_overlap_give_the_same_bits(ws, monkeypatch):
-    """WS_SLAB_OVERLAP=0 keeps halos and kernels on one stream (no early / late split); same result."""
-    monkeypatch.setenv("WS_SLAB_OVERLAP", "0")
+def test_slabs_without_halo_overlap_give_the_same_bits(ws):
+    """WS_FLAG_NO_OVERLAP keeps halos and kernels on one stream (no early / late split); same result."""
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(32768, 99, list(params.ext_min), list(params.ext_max))
     want = _single(ws, pos, params, 25)
-    got, _ = ws.slab.run_loopback(pos, params, 3, 25)
+    got, _ = ws.slab.run_loopback(pos, params, 3, 25, overlap=False)
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
 
@@ -226,12 +224,11 @@ def test_slab_step_only_enqueues(ws):
 
 
 @pytest.mark.parametrize("fixed", ["0", "1"])
-def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
+def test_message_sizes_follow_the_fluid(ws, fixed):
     """WS_FLAG_LAGGED_MESSAGES.  The buffers of a slab's messages have fixed capacities (sized for the violent phase of a collapsing cloud); what
     TRAVELS per step is a prefix sized from what every rank reported a few steps ago -- the same all-gathered table on
-    every rank, hence the same size at both ends of every exchange.  WS_SLAB_FIXED_MESSAGES=1 keeps the capacities.
+    every rank, hence the same size at both ends of every exchange.  WS_FLAG_FIXED_MESSAGES keeps the capacities.
     Either way the result is the single handle's, bit for bit."""
-    monkeypatch.setenv("WS_SLAB_FIXED_MESSAGES", fixed)
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
     steps, world = 40, 3
@@ -241,7 +238,7 @@ def test_message_sizes_follow_the_fluid(ws, monkeypatch, fixed):
         s.run(steps)
         return s.read_vec("particles"), s.stats()
 
-    res = ws.slab.run_loopback_program(pos, params, world, program, lagged_messages=True)
+    res = ws.slab.run_loopback_program(pos, params, world, program, lagged_messages=fixed == "0", fixed_messages=fixed == "1")
     for rec, st in res:
         for f in want.dtype.names:
             assert np.array_equal(rec[f].view(np.uint32), want[f].view(np.uint32)), f

@@ -13,11 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("overlap", ["0", "1"])
 def test_two_process_slabs_match_single_handle_bitwise(ws, tmp_path, overlap):
     steps = 30
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               WS_SLAB_OVERLAP=overlap)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     pattern = str(tmp_path / "slab_%d.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tests", "dist_slab_worker.py"), pattern, str(steps)]
+           "--master-port", "29533", os.path.join(ROOT, "tests", "dist_slab_worker.py"), pattern, str(steps), overlap]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))

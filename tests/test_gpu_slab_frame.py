@@ -144,13 +144,12 @@ def test_capacity_overrun_with_a_sync_after_every_step_still_fails_every_rank_at
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_particles_that_overshoot_the_padding_with_halo_overlap_on(ws, monkeypatch, world):
+def test_particles_that_overshoot_the_padding_with_halo_overlap_on(ws, world):
     """Predicted positions that leave the two cells of padding are clamped into the grid's border rows, whose
     linearised stencil wraps into the neighbouring LAYER -- for the first / last early layer of a slab a ghost layer,
     whose cell starts the halo stream is rewriting while the early range computes.  Early launches cut their runs to
     the owned range, so K4 and K5 number their candidates alike whatever the ghost starts hold: bit-identical to the
     single handle."""
-    monkeypatch.setenv("WS_SLAB_OVERLAP", "1")
     params = ws.make_params(container_size=(16.0, 9.0, 9.0))
     pos = ws.workloads.uniform_cloud(65536, 77, list(params.ext_min), list(params.ext_max))
     orc_like = np.zeros(pos.shape[0], ws.PARTICLE_DTYPE)

@@ -13,14 +13,14 @@ from util import assert_particles_close, oracle_from_params, oracle_one_step, re
 pytestmark = pytest.mark.gpu
 
 
-def _one_step_vs_oracle(oracle, ws, pos, params, label, state=None, ieee=False):
+def _one_step_vs_oracle(oracle, ws, pos, params, label, state=None, ieee=False, library=None):
     O = oracle
     orc = oracle_from_params(O, pos, params)
     st = orc.particles.copy() if state is None else state.astype(O.PARTICLE_DTYPE)
     want = oracle_one_step(O, orc, st, mode=O.SORT_FAST)
     ints = (orc.particle_cell_indicies.copy(), orc.sorted_keys().copy(), orc.cell_offsets.copy())
     rev = oracle_one_step(O, orc, st, reverse=True, mode=O.SORT_FAST)
-    w = ws.FluidWorker(pos, params, ieee_division=ieee)
+    w = ws.FluidWorker(pos, params, ieee_division=ieee, library=library)
     w.write_slice("particles", st)
     w.run()
     got = w.read_vec("particles")
@@ -66,32 +66,32 @@ def test_radius_key_presses_during_a_run_never_fail_and_stay_on_the_oracle(oracl
 
 @pytest.mark.parametrize("budget,axes", [("50000", "z"), ("2000", "zy"), ("64", "zyx")])
 @pytest.mark.parametrize("ieee", [False, True], ids=["hw-rcp-sqrt", "ieee-division"])
-def test_cells_merged_along_z_then_y_then_x(oracle, ws, monkeypatch, budget, axes, ieee):
-    """WS_CELL_BUDGET (a developer knob) forces the merge on a small domain so that every stage of it is exercised:
+def test_cells_merged_along_z_then_y_then_x(oracle, ws, devlib, monkeypatch, budget, axes, ieee):
+    """WS_CELL_BUDGET (an environment hook of the developer build, tests/libwsfluid_dev.so) forces the merge on a small domain so that every stage of it is exercised:
     z only, z and y, all three axes -- against the oracle, several teacher-forced steps into a collapse."""
     monkeypatch.setenv("WS_CELL_BUDGET", budget)
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(4.0, -9.8, 2.0, 0.0))
     pos = ws.workloads.uniform_cloud(65536, 12, list(params.ext_min), list(params.ext_max))
-    w = ws.FluidWorker(pos, params)
+    w = ws.FluidWorker(pos, params, library=devlib)
     w.run(25)
     state = w.read_vec("particles")
     merged = w.stats()["cells_merged"]
     w.close()
     assert [m > 1 for m in merged] == ["x" in axes, "y" in axes, "z" in axes], merged
-    _one_step_vs_oracle(oracle, ws, pos, params, "merged cells %s" % (merged,), state=state, ieee=ieee)
+    _one_step_vs_oracle(oracle, ws, pos, params, "merged cells %s" % (merged,), state=state, ieee=ieee, library=devlib)
 
 
 @pytest.mark.parametrize("budget", ["2000", "64"])
-def test_slabs_on_a_merged_grid_reproduce_the_single_handle(ws, monkeypatch, budget):
+def test_slabs_on_a_merged_grid_reproduce_the_single_handle(ws, devlib, monkeypatch, budget):
     """The slab cuts are expressed in grid layers along x -- merged ones too: bit-identical to the single handle."""
     monkeypatch.setenv("WS_CELL_BUDGET", budget)
     params = ws.make_params(container_size=(16.0, 9.0, 9.0), gravity=(6.0, -9.8, 0.0, 0.0))
     pos = ws.workloads.uniform_cloud(65536, 1234, list(params.ext_min), list(params.ext_max))
-    w = ws.FluidWorker(pos, params)
+    w = ws.FluidWorker(pos, params, library=devlib)
     w.run(30)
     want = w.read_vec("particles")
     w.close()
-    got, owned = ws.slab.run_loopback(pos, params, 3, 30)
+    got, owned = ws.slab.run_loopback(pos, params, 3, 30, library=devlib)
     assert sum(owned) == pos.shape[0]
     for f in want.dtype.names:
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f

@@ -17,7 +17,7 @@ for p in "$@"; do
   echo "applied $p"
 done
 src=$work/water-sandbox_amd/csrc
-/opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-unused-result $flags \
+/opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-value -Wno-unused-result -DWS_DEV_HOOKS $flags \
   -I $work/include -I $src -o $root/tools/ab/lib$name.so \
   $src/ws_kernels.hip $src/ws_api.cpp $src/ws_rccl.cpp $src/ws_local.cpp -ldl
 rm -rf $work

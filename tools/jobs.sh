@@ -1,0 +1,60 @@
+#!/bin/bash
+# The GPU jobs of a round, one name each (replaces the per-call command files of rounds 3-4).  Run through gpurun from
+# the repo root:   gpurun --timeout 1200 -- 'bash tools/jobs.sh <job> [args]'
+# Everything lands under gpurun_out/r05/; what is judged is copied into profiles/r05/ afterwards by hand.
+set -o pipefail
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
+export TMPDIR=/tmp
+R=r05
+out=gpurun_out/$R; mkdir -p $out
+job=$1; shift
+
+counters() {  # counters <cfg> <particles> <warm> <steps> : kernel trace + traffic + SQ/TA passes of one window
+  local cfg=$1 n=$2 warm=$3 steps=$4
+  tools/traffic.sh $cfg cloud $warm $steps && python3 tools/traffic_report.py $cfg cloud $warm $steps $n $out/traffic_$cfg.json > /dev/null
+  echo "traffic $cfg w$warm done"
+  tools/pmc.sh ${R}${cfg}w$warm $cfg cloud $warm $steps abc > $out/pmc_${cfg}_w$warm.log 2>&1
+  python3 tools/pmc_windows.py ${R}${cfg}w$warm $cfg cloud $warm $steps $out/pmc_windows_$cfg.json > /dev/null
+  echo "pmc $cfg w$warm done"
+}
+
+case $job in
+c4_counters)  # the north-star size under the counters, both windows
+  rm -rf $out/rocprof_c4
+  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rocprof_c4 -- python3 bench.py --config c4 --gpus 1 --steps 20 --warmup 5 --reps 1 --no-cpu-baseline --no-ieee --no-readback --no-north-star > $out/rocprof_c4.json 2> $out/rocprof_c4.err || exit 1
+  python3 tools/window_stats.py $(ls $out/rocprof_c4/*/*_kernel_trace.csv | head -1) 5 20 > $out/rocprof_c4_windows.json
+  cp $(ls $out/rocprof_c4/*/*_kernel_stats.csv | head -1) $out/rocprof_c4_kernel_stats.csv
+  echo "trace done"
+  counters c4 16777216 5 20
+  counters c4 16777216 400 100
+  ;;
+c3_counters)
+  counters c3 4194304 5 20
+  counters c3 4194304 400 100
+  ;;
+tests)
+  timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; rc=$?
+  echo "pytest exit $rc"; tail -5 $out/pytest_gpu.log; exit $rc
+  ;;
+bench)
+  timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err; rc=$?
+  echo "bench exit $rc"; tail -c 600 $out/bench_driver_cmd.json; exit $rc
+  ;;
+ablate)  # ablate <warm> <lib> [<lib> ...] : one step of each tools/ab/lib<name>.so from the same state
+  python3 tools/ablate.py "$@" 2>&1 | tee -a $out/ablate.log
+  ;;
+chunk_ab)  # chunk_ab <cfg> <state step> <steps> <chunks...>
+  python3 tools/chunk_ab.py "$@" 2>&1 | tee -a $out/chunk_ab.log
+  ;;
+chunk_trace)  # chunk_trace <cfg> <state step> <chunks> : kernel timeline of a few chunked steps
+  rm -rf $out/chunk_trace
+  rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/chunk_trace -- python3 tools/chunk_ab.py $1 $2 6 $3 > $out/chunk_trace.log 2>&1
+  python3 tools/chunk_timeline.py $(ls $out/chunk_trace/*/*_kernel_trace.csv | head -1) | tee $out/chunk_timeline_$1_$2_c$3.txt
+  ;;
+wg_timeline)  # wg_timeline <cfg> <state step>
+  python3 tools/wg_timeline.py "$@" 2>&1 | tee -a $out/wg_timeline.log
+  ;;
+*)
+  echo "unknown job $job"; exit 2
+  ;;
+esac

@@ -11,7 +11,7 @@ usage: traffic_report.py <config> <dist> <warmup> <steps> <particles> [out.json]
 import collections, csv, glob, json, os, sys
 cfg, dist, warm, steps, n = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_path = sys.argv[6] if len(sys.argv) > 6 else os.path.join(root, "profiles", "r04", "traffic.json")
+out_path = sys.argv[6] if len(sys.argv) > 6 else os.path.join(root, "profiles", "r05", "traffic.json")
 
 
 def per_kernel(kind, counter, scale):

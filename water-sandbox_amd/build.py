@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwsfluid.so")
 
 SOURCES = ["ws_kernels.hip", "ws_api.cpp", "ws_rccl.cpp", "ws_local.cpp"]
-HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
+HEADERS = [os.path.join(CSRC, "ws_internal.h"), os.path.join(CSRC, "ws_devhooks.h"), os.path.join(CSRC, "ws_slab.inc"), os.path.join(ROOT, "include", "wsfluid.h")]
 # Test-only build of the same sources plus the reference-order validation mode (tests/refcheck/: a literal HIP
 # restatement of the reference's six WGSL passes and its host glue, used by the tests as a second, independent
 # restatement).  Sources and binary live under tests/; it is built by __graft_entry__.build() and is never loaded by the
@@ -68,6 +68,19 @@ def build_refcheck_library(force=False, verbose=False):
     return _compile(REFCHECK_LIB, ["-DWS_WITH_REFCHECK", "-I", REFCHECK_DIR], verbose)
 
 
+# TEST-ONLY / developer build of the product sources with -DWS_DEV_HOOKS: the environment hooks of csrc/ws_devhooks.h
+# (WS_VARIANT, WS_CELL_BUDGET, WS_RCCL_LIBRARY, the message-size floors, stream priorities ...) exist in this build alone.
+# The tests that need one of them load it explicitly (tests/util.py dev_library()); the product library reads no
+# environment variable at all.
+DEV_LIB = os.path.join(ROOT, "tests", "libwsfluid_dev.so")
+
+
+def build_dev_library(force=False, verbose=False):
+    if not force and not _stale(DEV_LIB):
+        return DEV_LIB
+    return _compile(DEV_LIB, ["-DWS_DEV_HOOKS"], verbose)
+
+
 # TEST-ONLY: a stand-in for librccl (tests/fake_rccl/) whose "ranks" are host threads of one process on one GPU, so that
 # a one-GPU box can drive csrc/ws_rccl.cpp with real peers.  Loaded only when WS_RCCL_LIBRARY names it.
 FAKE_RCCL_SRC = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.hip")
@@ -88,4 +101,5 @@ def build_fake_rccl(force=False, verbose=False):
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
     print(build_refcheck_library(force=True, verbose=True))
+    print(build_dev_library(force=True, verbose=True))
     print(build_fake_rccl(force=True, verbose=True))

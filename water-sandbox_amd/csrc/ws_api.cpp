@@ -157,7 +157,7 @@ ws_status derive_dev(ws_handle *h, const ws_params &p, uint32_t n, WsDev *out)
     // runs stays canonical (multi-GPU bit-identity), and the only cost is more candidates for the distance test.
     // No smoothing radius the reference accepts runs out of table memory.
     uint64_t budget = std::max<uint64_t>(16ull * n, 1ull << 24);
-    if (const char *v = getenv("WS_CELL_BUDGET")) budget = std::max<uint64_t>(strtoull(v, nullptr, 10), 64);  // experiments
+    if (const char *v = WS_DEV_ENV("WS_CELL_BUDGET")) budget = std::max<uint64_t>(strtoull(v, nullptr, 10), 64);  // developer builds: force the merge on small domains
     budget = std::min<uint64_t>(budget, kMaxCells);
     for (int c = 2; c >= 0 && cells > budget; c--) {
         const uint64_t others = cells / (uint64_t)d.dim[c];
@@ -269,7 +269,7 @@ ws_status upload_mult(ws_handle *h)
 // kernel family and pair arithmetic of a new handle (flags already set)
 void configure_kernels(ws_handle *h)
 {
-    if (const char *v = getenv("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : WS_VARIANT_LISTED;
+    if (const char *v = WS_DEV_ENV("WS_VARIANT")) h->variant = strcmp(v, "simple") == 0 ? WS_VARIANT_SIMPLE : WS_VARIANT_LISTED;
     h->ieee = (h->flags & WS_FLAG_IEEE_DIVISION) != 0;
 }
 
@@ -432,6 +432,74 @@ void enqueue_step(ws_handle *h)
     h->accel_stale = true;  // ... and no accelerations (refresh_accel)
 }
 
+// The chunked single-GPU step.  The sort phase is global; then the sorted order is cut into
+// `chunks` ranges of whole x cell layers (x is the slowest sort axis: a range of layers is a contiguous range of slots,
+// delimited by two cell starts the kernels read on the device) and K4(c) / K5(c) run on two streams of their own:
+//     stream A:  K4(0) K4(1) K4(2) ...                K5(c) needs the densities of layers +-1: K4(c - 1), K4(c), K4(c + 1)
+//     stream B:        wait K4(1): K5(0)  wait K4(2): K5(1) ...
+// so that the VALU-bound radius sweep of one chunk and the gather-bound force walk of another share the CUs.  Same
+// kernels, same visit order, same per-particle arithmetic: bit-identical to the unchunked step.  Every chunk has at
+// least two cell layers, so the wrapped stencil cells of a border row (ws_kernels.hip, WsCut) stay inside chunk c + 1.
+// K5's epilogue writes cur / cid_cur / rank in place; nothing reads them before the next step's k_place, which waits
+// for all of it on `stream`.
+void enqueue_step_chunked(ws_handle *h)
+{
+    const WsDev &d = h->dev;
+    hipStream_t s = h->stream;
+    const uint32_t C = std::max(1u, std::min(h->chunks, (uint32_t)d.dim[0] / (h->chunk_comb ? 8u : 2u)));  // (a re-grid may have left fewer layers)
+    wsk_scan(s, h->count, h->start + d.guard, nullptr, h->bsum, d.ncells, true, 0);
+    wsk_place(s, d, h->cid_cur, h->cur.rank, h->cur.pos, h->start, h->slot_tmp, h->id_tmp);
+    wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
+    hipEventRecord(h->chunk_ev[0], s);
+    const int mode = h->chunk_mode;  // 0: K4 on one stream, K5 on one; 1: K4 on one, K5 on two; 2: K4 on two, K5 on two
+    hipStream_t k4s[2] = {h->chunk_stream[0], mode >= 2 ? h->chunk_stream[1] : h->chunk_stream[0]};
+    hipStream_t k5s[2] = {h->chunk_stream[2], mode >= 1 ? h->chunk_stream[3] : h->chunk_stream[2]};
+    hipStreamWaitEvent(k4s[0], h->chunk_ev[0], 0);
+    if (k4s[1] != k4s[0]) hipStreamWaitEvent(k4s[1], h->chunk_ev[0], 0);
+    const uint32_t rowy = (uint32_t)(d.dim[1] * d.dim[2]), nx = (uint32_t)d.dim[0];
+    const bool comb = h->chunk_comb;
+    auto chunk_dev = [&](uint32_t c) {
+        WsDev dc = d;
+        if (comb) {
+            // chunk c = the c-th part of EVERY XCD's x-slab (even slabs ascending, odd slabs descending, so that the parts
+            // that meet at a slab boundary belong to the same chunk: the neighbours of chunk c lie in chunks c - 1 .. c + 1)
+            dc.chunk_on = 2;
+            for (uint32_t x = 0; x < 8; x++) {
+                const uint32_t s0 = (uint32_t)((uint64_t)x * nx / 8), s1 = (uint32_t)((uint64_t)(x + 1) * nx / 8), nl = s1 - s0;
+                const uint32_t cc = (x & 1u) ? C - 1u - c : c;
+                dc.seg_c0[x] = (uint32_t)d.guard + (s0 + (uint32_t)((uint64_t)cc * nl / C)) * rowy;
+                dc.seg_c1[x] = (uint32_t)d.guard + (s0 + (uint32_t)((uint64_t)(cc + 1) * nl / C)) * rowy;
+            }
+            dc.n = (uint32_t)std::min<double>(d.n, h->chunk_grid_frac * d.n / (8.0 * C) + 256.0);  // estimated length of one range
+            return dc;
+        }
+        dc.chunk_on = 1;
+        dc.chunk_c0 = (uint32_t)d.guard + (uint32_t)((uint64_t)c * nx / C) * rowy;
+        dc.chunk_c1 = (uint32_t)d.guard + (uint32_t)((uint64_t)(c + 1) * nx / C) * rowy;
+        if (const char *v = WS_DEV_ENV("WS_CHUNK_GRID_FRAC"))  // EXPERIMENT: launch bound as a fraction of N / C (no overflow handling yet)
+            dc.n = (uint32_t)std::min<double>(d.n, atof(v) * d.n / C + 4096.0);
+        return dc;
+    };
+    for (uint32_t c = 0; c < C; c++) {
+        wsk_density(k4s[c & 1], chunk_dev(c), h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->ieee, h->stats, h->mask, h->sxyz);
+        hipEventRecord(h->chunk_ev[1 + c], k4s[c & 1]);
+    }
+    for (uint32_t c = 0; c < C; c++) {
+        hipStream_t sk = k5s[c & 1];
+        for (uint32_t q = c ? c - 1 : 0; q <= std::min(c + 1, C - 1); q++) hipStreamWaitEvent(sk, h->chunk_ev[1 + q], 0);
+        wsk_force(sk, chunk_dev(c), h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
+                  h->variant, h->ieee, h->mask, false);
+    }
+    hipEventRecord(h->chunk_ev[C + 1], k5s[0]);
+    hipStreamWaitEvent(s, h->chunk_ev[C + 1], 0);
+    if (k5s[1] != k5s[0]) {
+        hipEventRecord(h->chunk_ev[C + 2], k5s[1]);
+        hipStreamWaitEvent(s, h->chunk_ev[C + 2], 0);
+    }
+    h->pred_stale = true;
+    h->accel_stale = true;
+}
+
 // cur.pred is not maintained by the step loop (k_reorder recomputes it): bring it up to date for a reader off the loop
 void refresh_pred(ws_handle *h, const WsDev &d)
 {
@@ -538,6 +606,13 @@ void free_all(ws_handle *h)
         hipStreamSynchronize(h->copy_stream);
         hipStreamDestroy(h->copy_stream);
     }
+    for (hipStream_t cs : h->chunk_stream)
+        if (cs) {
+            hipStreamSynchronize(cs);
+            hipStreamDestroy(cs);
+        }
+    for (hipEvent_t e : h->chunk_ev)
+        if (e) hipEventDestroy(e);
     if (h->rb_gathered) hipEventDestroy(h->rb_gathered);
     if (h->rb_done) hipEventDestroy(h->rb_done);
     hipFree(h->rb_stage);
@@ -754,6 +829,23 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_TRY(alloc_grid(h));
     CREATE_TRY(upload_mult(h));
     CREATE_TRY(upload_positions(h, pos_xyz));
+    if (const char *v = WS_DEV_ENV("WS_CHUNKS")) {
+        h->chunks = (uint32_t)std::max(1, std::min(atoi(v), h->dev.dim[0] / 2));
+        if (h->chunks > 1) {
+            // K4's streams at the highest priority: the producer runs ahead, and streams of another priority never
+            // share a hardware queue with the step's and K5's streams (queues are pooled per priority)
+            int lo = 0, hi = 0;
+            CREATE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const bool flat = WS_DEV_ENV("WS_CHUNK_FLAT_PRIORITY") != nullptr;
+            for (int k = 0; k < 4; k++)
+                CREATE_HIP(hipStreamCreateWithPriority(&h->chunk_stream[k], hipStreamNonBlocking, (k < 2 && !flat) ? hi : 0));
+            if (const char *m = WS_DEV_ENV("WS_CHUNK_MODE")) h->chunk_mode = atoi(m);
+            if (const char *m = WS_DEV_ENV("WS_CHUNK_COMB")) h->chunk_comb = atoi(m) != 0;
+            if (const char *m = WS_DEV_ENV("WS_CHUNK_GRID_FRAC")) h->chunk_grid_frac = atof(m);
+            h->chunk_ev.resize(h->chunks + 3, nullptr);
+            for (hipEvent_t &e : h->chunk_ev) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = h;
@@ -820,7 +912,8 @@ ws_status ws_step(ws_handle *h)
             return WS_OK;
         }
     }
-    enqueue_step(h);
+    if (h->chunks > 1 && h->pred_stale && !h->alias && h->variant == WS_VARIANT_LISTED) enqueue_step_chunked(h);
+    else enqueue_step(h);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));
     h->done_recorded = true;
@@ -953,7 +1046,7 @@ ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
         // wait-for-the-copy barrier in front of the next step's kernels -- copy and step then run in series.  Queues
         // are pooled per priority, so this stream can never share one with the step.
         int lo = 0, hi = 0;
-        const char *pr = getenv("WS_COPY_STREAM_PRIORITY");  // "default" = same priority as the step's stream (A/B runs)
+        const char *pr = WS_DEV_ENV("WS_COPY_STREAM_PRIORITY");  // "default" = same priority as the step's stream (A/B runs)
         if (pr && strcmp(pr, "default") == 0) {
             HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
         } else {

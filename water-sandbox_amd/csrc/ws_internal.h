@@ -9,6 +9,8 @@
 
 #include "wsfluid.h"
 
+#include "ws_devhooks.h"
+
 // Everything a kernel needs besides array pointers; passed by value (kernarg / SGPRs).
 // Slab handles: where the force kernel's epilogue puts a particle whose new predicted position left the slab
 // (one copy in device memory, WsDev::mig points at it)
@@ -59,6 +61,12 @@ struct WsDev {
     uint32_t has_left, has_right;  // x-neighbours present
     uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
     const WsMig *mig;              // device copy; non-null = the force epilogue also does migration part 1
+    // A launch that covers ONE x-chunk of a single-GPU handle's sorted order (the chunked step: enqueue_step_chunked):
+    // the particles of the cell layers whose cell starts are start[chunk_c0] .. start[chunk_c1] (indices into the table
+    // INCLUDING its guard).  chunk_on == 0: the whole range.
+    uint32_t chunk_on, chunk_c0, chunk_c1;
+    // chunk_on == 2 ("comb"): eight ranges, one per XCD (workgroup b works for XCD b & 7): start[seg_c0[x]] .. start[seg_c1[x]]
+    uint32_t seg_c0[8], seg_c1[8];
     uint32_t mig_limit;            // records the NEXT step's migration messages will carry (<= WsMig::mig_cap; 0 = all of it)
     uint32_t far_limit;            // ... and each of its far messages (<= WsMig::far_cap; 0 = all of it)
 };
@@ -97,7 +105,7 @@ enum { WS_RANGE_ALL = 0, WS_RANGE_EARLY = 1, WS_RANGE_LATE_LEFT = 2, WS_RANGE_LA
 #define WS_MIG_REC_WORDS_HOST 8u  // = WS_MIG_REC_WORDS of ws_kernels.hip: {pos, id}, {vel, 0}
 #define WS_HDR_UNKNOWN 0xFFFFFFFFu  // header words 4 / 5 before the first migration / halo of a particle set has been counted
 
-// density / force kernel family (WS_VARIANT=simple in the environment, for A/B tests)
+// density / force kernel family (developer builds: WS_VARIANT=simple in the environment, for A/B tests)
 enum { WS_VARIANT_SIMPLE = 0, WS_VARIANT_LISTED = 2 };
 
 // Accept masks K4 writes and K5 walks: bit s of owned particle p (sorted order, p = index - base) = its s-th
@@ -221,6 +229,14 @@ struct ws_handle {
     WsRef ref;
 #endif
 
+    // The chunked step (single-GPU handles): K4 / K5 of different x-chunks side by side on two more streams
+    uint32_t chunks = 1;                   // 1 = the five launches one after another on `stream`
+    int chunk_mode = 2;
+    bool chunk_comb = false;
+    double chunk_grid_frac = 1.6;
+    hipStream_t chunk_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // K4 even / odd chunks, K5 even / odd chunks
+    std::vector<hipEvent_t> chunk_ev;      // [0] sorted, [1 .. chunks] K4(c) done, [chunks + 1], [chunks + 2] the K5 streams' ends
+
     // WS_FLAG_GRAPH on a single-GPU handle: the captured steady-state step
     hipGraphExec_t graph_exec = nullptr;
     bool graph_failed = false;
@@ -271,7 +287,8 @@ struct WsSlab {
     uint32_t exact_now[3] = {0, 0, 0};  // the records the last step's migration / halo / far messages carried
     uint32_t size_waits = 0;            // host waits for message sizes so far (two per step with exact sizes)
     uint32_t limit_hold = 0;          // steps for which the limits stay at the full capacities (after a load / parameter change)
-    bool fixed_messages = false;      // WS_SLAB_FIXED_MESSAGES=1: always the full capacities (rounds 1-3)
+    bool fixed_messages = false;      // WS_FLAG_FIXED_MESSAGES (and a captured step with peers): always the full capacities
+    uint32_t mode_word = 0;           // every choice that fixes the step's collective sequence or its results: all ranks must agree (slab_agree_mode)
     std::vector<uint32_t> cuts;       // world + 1 global x-layer cuts
     uint32_t *cuts_dev = nullptr;
     uint32_t *dyn = nullptr;          // WS_DYN_WORDS device words (DY_*)

@@ -98,7 +98,13 @@ struct WsSpan {
 __device__ __forceinline__ WsSpan ws_span(const WsDev &d, const uint32_t *__restrict__ start)
 {
     WsSpan sp = {d.base, d.n, 0xFFFFFFFFu, 0u};
-    if (!d.dyn) return sp;
+    if (!d.dyn) {
+        if (d.chunk_on) {  // one x-chunk of a single-GPU handle: a contiguous range between two cell starts
+            sp.lo = start[d.chunk_c0];
+            sp.len = start[d.chunk_c1] - sp.lo;
+        }
+        return sp;
+    }
     const uint32_t n = d.dyn[DY_N], end = d.base + n;
     sp.len = n;
     if (d.range_sel == WS_RANGE_ALL) return sp;
@@ -1021,18 +1027,14 @@ __device__ __forceinline__ void nd_run_planar(const WsDev &d, float4 o, uint32_t
     }
 }
 
+// One tile of K4: lane `threadIdx.x` works for particle iv (lanes past the end of their range shadow its last particle,
+// valid = false).  `list`: the workgroup's LDS columns.
 template <bool IEEE, bool CUT>
-__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ start,
-                                                         const uint32_t *__restrict__ cid_srt, WsSorted srt, WsXYZ sxyz,
-                                                         WsMask mask, uint32_t *__restrict__ stats)
+__device__ __forceinline__ void nd_tile(const WsDev &d, const uint32_t *__restrict__ start, const uint32_t *__restrict__ cid_srt,
+                                        WsSorted srt, WsXYZ sxyz, WsMask mask, uint32_t *__restrict__ stats, float *list,
+                                        const uint32_t iv, const bool valid, const uint32_t tid)
 {
-    __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
-    const WsSpan sp = ws_span(d, start);
-    const uint32_t ntiles = (sp.len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
-    if (blockIdx.x >= ntiles) return;
-    const uint32_t v = xcd_tile(blockIdx.x, ntiles) * ND_P + threadIdx.x;
-    const bool valid = v < sp.len;
-    const uint32_t iv = span_at(sp, valid ? v : sp.len - 1u), i = iv;  // lanes past the end shadow the last particle
+    const uint32_t i = iv;
     const float4 o = make_float4(sxyz.x[iv], sxyz.y[iv], sxyz.z[iv], 0.f);  // the planar copy: coalesced, same bits
     const int c = (int)cid_srt[iv];
     const int rowz = d.dim[2], rowy = d.dim[1] * d.dim[2];
@@ -1043,15 +1045,15 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     uint32_t acc32 = 0;
     uint32_t pos = 0, word = 0;  // candidates seen so far = 32 * word + pos
     uint32_t *mrow = mask.words + (iv - d.base);
-    auto push = [&](uint32_t slot, float d2) { list[slot * ND_P + threadIdx.x] = d2; };
+    auto push = [&](uint32_t slot, float d2) { list[slot * ND_P + tid] = d2; };
     auto phase2 = [&](uint32_t cnt) {
         uint32_t k = 0;
         for (; k + 2u <= cnt; k += 2u) {  // two list entries per pass: their LDS reads and square roots overlap
-            const float a = list[k * ND_P + threadIdx.x], b = list[(k + 1u) * ND_P + threadIdx.x];
+            const float a = list[k * ND_P + tid], b = list[(k + 1u) * ND_P + tid];
             density_pair<IEEE>(d, a, density, near_density, 1u);
             density_pair<IEEE>(d, b, density, near_density, 1u);
         }
-        if (k < cnt) density_pair<IEEE>(d, list[k * ND_P + threadIdx.x], density, near_density, 1u);
+        if (k < cnt) density_pair<IEEE>(d, list[k * ND_P + tid], density, near_density, 1u);
     };
     auto note = [&](uint32_t nvalid, uint32_t bits) {
         acc32 |= bits << pos;
@@ -1091,6 +1093,37 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     }
 }
 
+// COMB = false: the whole range, or the span a slab launch names (ws_span); tiles dealt XCD-contiguously.
+// COMB = true: one chunk of the chunked single-GPU step -- eight ranges of the sorted order, one per XCD (the XCD keeps
+// its x-slab of the domain over all chunks: its L2 sees the same neighbourhood the unchunked launch shows it); workgroup b
+// works for XCD b & 7 and takes that range's tiles (b >> 3), (b >> 3) + gridDim.x / 8, ... : the grid is sized from an
+// ESTIMATE of the ranges' lengths (they are known on the device only), the loop covers whatever they really are.
+template <bool IEEE, bool CUT, bool COMB>
+__global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ start,
+                                                         const uint32_t *__restrict__ cid_srt, WsSorted srt, WsXYZ sxyz,
+                                                         WsMask mask, uint32_t *__restrict__ stats)
+{
+    __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
+    if constexpr (COMB) {
+        const uint32_t x = blockIdx.x & 7u;
+        const uint32_t lo = start[d.seg_c0[x]], len = start[d.seg_c1[x]] - lo;
+        for (uint32_t j = blockIdx.x >> 3; j * ND_P < len; j += gridDim.x >> 3) {
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));  // nothing that depends on the lane is carried around the loop (registers)
+            const uint32_t v = j * ND_P + tid;
+            const bool valid = v < len;
+            nd_tile<IEEE, CUT>(d, start, cid_srt, srt, sxyz, mask, stats, list, lo + (valid ? v : len - 1u), valid, tid);
+        }
+    } else {
+        const WsSpan sp = ws_span(d, start);
+        const uint32_t ntiles = (sp.len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
+        if (blockIdx.x >= ntiles) return;
+        const uint32_t v = xcd_tile(blockIdx.x, ntiles) * ND_P + threadIdx.x;
+        const bool valid = v < sp.len;
+        nd_tile<IEEE, CUT>(d, start, cid_srt, srt, sxyz, mask, stats, list, span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x);  // lanes past the end shadow the last particle
+    }
+}
+
 #ifndef NF_WORDSYNC_MAX
 #define NF_WORDSYNC_MAX 8  // mask words per particle up to which a wave takes the word-synchronous walk.  Settled K5 at
 #endif                     // 8 / 10 words: C3 0.911 / 0.891 ms, but C2 0.068 / 0.085 ms -- 8 is the safe side
@@ -1098,21 +1131,15 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
 #endif
 
+// One tile of K5 (see nd_tile).  t_end / t_delta: the workgroup's LDS, a per-lane run table: candidate numbers
+// [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
 template <bool IEEE, bool ACCEL_ONLY, bool CUT>
-__global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
-                                                       const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
-                                                       float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                       uint32_t *__restrict__ count, WsMask mask)
+__device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restrict__ start, const uint32_t *__restrict__ cid_srt,
+                                        WsSorted srt, WsSoA out, float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                        uint32_t *__restrict__ count, WsMask mask, uint32_t *t_end, uint32_t *t_delta,
+                                        const uint32_t iv, const bool valid, const uint32_t tid)
 {
-    // per-lane run table: candidate numbers [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
-    __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
-    __shared__ uint32_t t_delta[9 * NF_P];
-    const WsSpan sp = ws_span(d, start);
-    const uint32_t ntiles = (sp.len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
-    if (blockIdx.x >= ntiles) return;
-    const uint32_t v = xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
-    const bool valid = v < sp.len;
-    const uint32_t iv = span_at(sp, valid ? v : sp.len - 1u), i = iv;  // lanes past the end shadow the last particle
+    const uint32_t i = iv;
     const float4 o = srt.pred(iv);   // w = own density
     const float4 vel = srt.vel(iv);  // w = own near density
     const float pressure = d.pressure_scalar * (o.w - d.target_density);
@@ -1136,12 +1163,12 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const int r = 3 * p + q;
-                t_delta[r * NF_P + threadIdx.x] = b[q] - total;
+                t_delta[r * NF_P + tid] = b[q] - total;
                 total += e[q] - b[q];
-                t_end[r * NF_P + threadIdx.x] = total;
+                t_end[r * NF_P + tid] = total;
             }
         }
-        t_end[9 * NF_P + threadIdx.x] = 0xFFFFFFFFu;
+        t_end[9 * NF_P + tid] = 0xFFFFFFFFu;
         if (!valid) total = 0;
     }
     // A particle with more candidates than the accept mask holds (> 2 048: a cell column of the settled floor layer in the
@@ -1152,8 +1179,8 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     if (!over) {
         const uint32_t *mrow = mask.words + (iv - d.base);
         const uint32_t nwords = (total + 31u) >> 5;
-        uint32_t run = 0, end_r = t_end[threadIdx.x], delta_r = t_delta[threadIdx.x];
-        const uint32_t self_s = i - t_delta[4 * NF_P + threadIdx.x];  // own candidate number (own cell = run 4)
+        uint32_t run = 0, end_r = t_end[tid], delta_r = t_delta[tid];
+        const uint32_t self_s = i - t_delta[4 * NF_P + tid];  // own candidate number (own cell = run 4)
       if (!any_over && !__ballot(nwords > (uint32_t)NF_WORDSYNC_MAX)) {
         // A wave whose particles all have few candidates (the sparse state: 1-2 mask words each) walks its 64 masks
         // WORD BY WORD, all lanes on the same word number: inside a word every lane takes its set bits one per
@@ -1178,8 +1205,8 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
                     bits &= bits - 1u;
                     while (sc >= end_r) {
                         run++;
-                        end_r = t_end[run * NF_P + threadIdx.x];
-                        delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
+                        end_r = t_end[run * NF_P + tid];
+                        delta_r = t_delta[min(run, 8u) * NF_P + tid];
                     }
                     const uint32_t j = sc + delta_r;
                     q_n = srt.pred_near(j);
@@ -1222,8 +1249,8 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
             rest &= rest - 1u;
             while (sc >= end_r) {
                 run++;
-                end_r = t_end[run * NF_P + threadIdx.x];
-                delta_r = t_delta[min(run, 8u) * NF_P + threadIdx.x];
+                end_r = t_end[run * NF_P + tid];
+                delta_r = t_delta[min(run, 8u) * NF_P + tid];
             }
             j = sc + delta_r;
             return true;
@@ -1251,6 +1278,37 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
     if (valid) force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
+// (COMB: see k_density_listed)
+template <bool IEEE, bool ACCEL_ONLY, bool CUT, bool COMB>
+__global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
+                                                       const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
+                                                       float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
+                                                       uint32_t *__restrict__ count, WsMask mask)
+{
+    __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
+    __shared__ uint32_t t_delta[9 * NF_P];
+    if constexpr (COMB) {
+        const uint32_t x = blockIdx.x & 7u;
+        const uint32_t lo = start[d.seg_c0[x]], len = start[d.seg_c1[x]] - lo;
+        for (uint32_t j = blockIdx.x >> 3; j * NF_P < len; j += gridDim.x >> 3) {
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));  // nothing that depends on the lane is carried around the loop (registers)
+            const uint32_t v = j * NF_P + tid;
+            const bool valid = v < len;
+            nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
+                                           lo + (valid ? v : len - 1u), valid, tid);
+        }
+    } else {
+        const WsSpan sp = ws_span(d, start);
+        const uint32_t ntiles = (sp.len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
+        if (blockIdx.x >= ntiles) return;
+        const uint32_t v = xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
+        const bool valid = v < sp.len;
+        nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
+                                       span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x);  // lanes past the end shadow the last particle
+    }
+}
+
 uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
 
 // ev (optional): the launch carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch packet's
@@ -1272,9 +1330,11 @@ static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start,
     else if (variant == WS_VARIANT_SIMPLE)
         WS_LAUNCH((k_density_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
     else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
-        WS_LAUNCH((k_density_listed<IEEE, true>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
+        WS_LAUNCH((k_density_listed<IEEE, true, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
+    else if (d.chunk_on == 2)  // d.n = the estimated length of ONE of the eight ranges
+        WS_LAUNCH((k_density_listed<IEEE, false, true>), dim3(8u * cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
     else
-        WS_LAUNCH((k_density_listed<IEEE, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
+        WS_LAUNCH((k_density_listed<IEEE, false, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
 }
 
 template <bool IEEE, bool ACCEL_ONLY>
@@ -1289,10 +1349,13 @@ static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, c
         WS_LAUNCH((k_force_simple<false, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt,
                   srt, out, accel, cid_out, count, mult);
     else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, true>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, true, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask);
+    else if (d.chunk_on == 2)  // d.n = the estimated length of ONE of the eight ranges
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, true>), dim3(8u * cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
                   accel, cid_out, count, mask);
     else
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
                   accel, cid_out, count, mask);
 }
 

@@ -168,6 +168,7 @@ ws_status ws_local_transport_create(void *hub, uint32_t rank, ws_transport *out)
     if (!h || !out || rank >= h->world) return WS_ERR_INVALID_ARG;
     LocalTransport *t = new (std::nothrow) LocalTransport{h, rank};
     if (!t) return WS_ERR_OUT_OF_MEMORY;
+    out->struct_size = sizeof(ws_transport);
     out->ctx = t;
     out->sendrecv = local_sendrecv;
     out->allgather_dev = local_allgather;

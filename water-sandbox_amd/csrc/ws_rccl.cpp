@@ -4,6 +4,7 @@
 // RCCL is loaded at run time (dlopen), so the library has no link-time dependency on it and single-GPU use
 // never touches it.  The host distributes rank 0's unique id (128 bytes) by whatever means it has.
 #include "wsfluid.h"
+#include "ws_devhooks.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -52,9 +53,10 @@ bool sym(F &fn, const char *name)
 bool load_rccl()
 {
     std::call_once(g_once, [] {
-        // WS_RCCL_LIBRARY: another library with RCCL's interface, by path (a site's own build; the test suite's
-        // one-process stand-in, tests/fake_rccl/).  Never a default: unset, only librccl is looked for.
-        const char *override_path = getenv("WS_RCCL_LIBRARY");
+        // Developer builds only (-DWS_DEV_HOOKS): WS_RCCL_LIBRARY names another library with RCCL's interface, by path
+        // -- the test suite's one-process stand-in, tests/fake_rccl/.  The product library looks for librccl alone: no
+        // environment variable can put another collective library under a production process.
+        const char *override_path = WS_DEV_ENV("WS_RCCL_LIBRARY");
         if (override_path && *override_path) {
             g_api.lib = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
         } else {
@@ -191,7 +193,7 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
         delete t;
         return WS_ERR_COMM;
     }
-    const char *single = getenv("WS_RCCL_SINGLE_COMM");
+    const char *single = WS_DEV_ENV("WS_RCCL_SINGLE_COMM");  // (developer builds: both streams on one communicator)
     if (g_api.CommSplit && !(single && atoi(single) != 0)) {
         // collective over the first communicator; same colour everywhere, ranks keep their order
         // (not fatal: without a second communicator both streams share the first one, as before round 3)
@@ -200,6 +202,7 @@ ws_status ws_rccl_transport_create(const void *unique_id, uint32_t rank, uint32_
             t->comm[1] = nullptr;
         }
     }
+    out->struct_size = sizeof(ws_transport);
     out->ctx = t;
     out->sendrecv = rccl_sendrecv;
     out->allgather_dev = rccl_allgather;

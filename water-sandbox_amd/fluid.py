@@ -33,6 +33,10 @@ WS_FLAG_IEEE_DIVISION = 4
 WS_FLAG_GRAPH = 8
 WS_FLAG_EXACT_MESSAGES = 16
 WS_FLAG_LAGGED_MESSAGES = 32
+WS_FLAG_FIXED_MESSAGES = 64
+WS_FLAG_NO_OVERLAP = 128
+WS_FLAG_GRAPH_MULTIRANK = 256
+WS_ABI_VERSION = 2
 KERNEL_IDS = {"cell_scan": 0, "cell_scatter": 1, "reorder": 2, "density": 3, "force_integrate_bin": 4, "bin": 5}
 
 # every symbol include/wsfluid.h declares (tests check the library exports all of them)

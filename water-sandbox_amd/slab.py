@@ -28,13 +28,13 @@ ALLGATHER_DEV_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_u
 
 
 class WsTransport(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_dev", ALLGATHER_DEV_T),
+    _fields_ = [("struct_size", C.c_uint64), ("ctx", C.c_void_p), ("sendrecv", SENDRECV_T), ("allgather_dev", ALLGATHER_DEV_T),
                 ("alltoall_dev", ALLGATHER_DEV_T)]  # (the same signature)
 
 
-def assign(params, positions, world_size):
+def assign(params, positions, world_size, library=None):
     """ws_slab_assign: the slab (rank) that owns each position at t = 0."""
-    L = fluid.load_library()
+    L = library if library is not None else fluid.load_library()
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     out = np.empty(positions.shape[0], np.uint32)
     L.ws_slab_assign.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -50,7 +50,7 @@ class _TransportBase:
     def __init__(self):
         self.error = None
         self._thunks = (SENDRECV_T(self._c_sendrecv), ALLGATHER_DEV_T(self._c_allgather_dev), ALLGATHER_DEV_T(self._c_alltoall_dev))
-        self.struct = WsTransport(None, *self._thunks)
+        self.struct = WsTransport(C.sizeof(WsTransport), None, *self._thunks)
 
     def _guard(self, fn, *a):
         try:
@@ -164,8 +164,8 @@ class NativeRcclTransport:
     """The transport inside the library (csrc/ws_rccl.cpp): RCCL send/recv groups, all-to-alls and all-gathers issued by the
     C++ side itself -- no Python in the step.  The host only moves rank 0's 128-byte unique id to every rank."""
 
-    def __init__(self, unique_id, rank, world, device):
-        L = self._L = fluid.load_library()
+    def __init__(self, unique_id, rank, world, device, library=None):
+        L = self._L = library if library is not None else fluid.load_library()
         L.ws_rccl_transport_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(WsTransport)]
         L.ws_rccl_transport_destroy.argtypes = [C.POINTER(WsTransport)]
         L.ws_rccl_last_error.restype = C.c_char_p
@@ -177,8 +177,8 @@ class NativeRcclTransport:
             raise fluid.WsError(st, "ws_rccl_transport_create: " + (L.ws_rccl_last_error() or b"").decode())
 
     @staticmethod
-    def unique_id():
-        L = fluid.load_library()
+    def unique_id(library=None):
+        L = library if library is not None else fluid.load_library()
         L.ws_rccl_unique_id.argtypes = [C.c_char_p]
         L.ws_rccl_last_error.restype = C.c_char_p
         buf = C.create_string_buffer(128)
@@ -308,8 +308,9 @@ class SlabWorker:
     """One x-slab of the domain on one GPU (ws_slab_create / ws_step / ws_slab_read_particles)."""
 
     def __init__(self, positions, ids, n_global, params, rank, world, transport, device=0, stream=None, profile=False,
-                 capacity=0, ghost_capacity=0, ieee_division=False, graph=False, exact_messages=False, lagged_messages=False):
-        L = self._L = fluid.load_library()
+                 capacity=0, ghost_capacity=0, ieee_division=False, graph=False, exact_messages=False, lagged_messages=False,
+                 fixed_messages=False, overlap=True, graph_multirank=False, library=None):
+        L = self._L = library if library is not None else fluid.load_library()
         L.ws_slab_create.argtypes = [C.POINTER(fluid.WsParams), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                      C.POINTER(fluid.WsDeviceCfg), C.POINTER(WsTransport), C.POINTER(C.c_void_p)]
         L.ws_slab_read_particles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -323,7 +324,9 @@ class SlabWorker:
         cfg.device, cfg.rank, cfg.world_size = device, rank, world
         cfg.flags = ((fluid.WS_FLAG_PROFILE if profile else 0) | (fluid.WS_FLAG_IEEE_DIVISION if ieee_division else 0)
                      | (fluid.WS_FLAG_GRAPH if graph else 0) | (fluid.WS_FLAG_EXACT_MESSAGES if exact_messages else 0)
-                     | (fluid.WS_FLAG_LAGGED_MESSAGES if lagged_messages else 0))
+                     | (fluid.WS_FLAG_LAGGED_MESSAGES if lagged_messages else 0)
+                     | (fluid.WS_FLAG_FIXED_MESSAGES if fixed_messages else 0) | (0 if overlap else fluid.WS_FLAG_NO_OVERLAP)
+                     | (fluid.WS_FLAG_GRAPH_MULTIRANK if graph_multirank else 0))
         cfg.capacity, cfg.ghost_capacity = capacity, ghost_capacity
         cfg.stream = stream
         self.params = params
@@ -476,7 +479,7 @@ def run_loopback_program(positions, params, world, program, device=0, **kw):
     leaves a collective alone."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     n = positions.shape[0]
-    owner = assign(params, positions, world)
+    owner = assign(params, positions, world, kw.get("library"))
     hub = LoopbackHub(world)
     results, errors = [None] * world, []
 
@@ -502,7 +505,7 @@ def run_loopback_program(positions, params, world, program, device=0, **kw):
 
 def run_loopback(positions, params, world, steps, device=0, ieee_division=False, capacity=0, ghost_capacity=0,
                  collect_errors=False, counters=None, change_params=None, sync_every_step=False, state=None,
-                 exact_messages=False, lagged_messages=False):
+                 exact_messages=False, lagged_messages=False, **worker_kw):
     """Step `world` slabs of one domain inside this process (one thread per slab) and return the
     particles of all slabs merged into original-id order.  Test helper for one-GPU boxes.
     collect_errors: instead of raising, return {rank: (steps completed, exception)} for the slabs whose ws_step
@@ -514,7 +517,7 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
     state: 80-byte records (original-id order) to start from instead of positions at rest."""
     positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     n = positions.shape[0]
-    owner = assign(params, positions, world)
+    owner = assign(params, positions, world, worker_kw.get("library"))
     hub = LoopbackHub(world)
     out = np.zeros(n, fluid.PARTICLE_DTYPE)
     seen = np.zeros(n, np.int32)
@@ -526,7 +529,7 @@ def run_loopback(positions, params, world, steps, device=0, ieee_division=False,
             sel = np.flatnonzero(owner == r).astype(np.uint32)
             w = SlabWorker(positions[sel], sel, n, params, r, world, hub.transport(r), device=device,
                            ieee_division=ieee_division, capacity=capacity, ghost_capacity=ghost_capacity,
-                           exact_messages=exact_messages, lagged_messages=lagged_messages)
+                           exact_messages=exact_messages, lagged_messages=lagged_messages, **worker_kw)
             if state is not None:
                 w.write_particles(state)
             if collect_errors:
