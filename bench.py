@@ -52,16 +52,17 @@ HBM_COPY_GBS = 6290.0  # achievable: float4 copy measured on MI355X (MI355X_MICR
 C3_PARTICLES = 4194304
 SETTLED_FROM = 400     # first step of the settled window
 SETTLED_STEPS = 100
-PROFILES_ROUND = "r04"
+PROFILES_ROUND = "r05"
 PROFILES = os.path.join(ROOT, "profiles", PROFILES_ROUND)
 # VALU issue peak of the chip: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (a packed-f32 or
 # transcendental instruction takes more: the fraction below is a lower bound of how busy the VALU issue ports are)
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
-# the step loop's instantiations as rocprofv3 names them: K4 <IEEE = false, CUT = false>, K5 <IEEE = false, ACCEL_ONLY =
-# false, CUT = false> (CUT: the early launches of a slab step)
-# (k_scan<ZERO = true, cells per thread>: 64 from 2^21 cells on, 32 below)
+# the step loop's instantiations as rocprofv3 names them (prefixes): K4 <IEEE = false, CUT = false, SCHED>, K5 <IEEE =
+# false, ACCEL_ONLY = false, CUT = false, SCHED> (CUT: the early launches of a slab step; SCHED: the
+# cost-guided tile schedule of handles of 2^17 .. 2^20 particles); k_scan<ZERO = true, cells per thread>: 64 from 2^21
+# cells on, 32 below
 STEP_KERNELS = {"cell_scan": "k_scan<true", "cell_scatter": "k_place", "reorder": "k_reorder<true>",
-                "density": "k_density_listed<false, false>", "force_integrate_bin": "k_force_listed<false, false, false>"}
+                "density": "k_density_listed<false, false,", "force_integrate_bin": "k_force_listed<false, false, false,"}
 
 
 def _by_kernel(table, name):
@@ -141,6 +142,33 @@ def cpu_baseline(pos, params, steps):
         "reference WGSL, fast sort mode; %d OpenMP threads = every core this process may use: %s)"
         % (steps, orc.n, O.default_threads(), why),
     }
+
+
+def cpu_baseline_other_configs():
+    """SURVEY 8(d)'s other CPU rows next to the benchmarked one: C1 with one thread in the exact sort
+    mode (the bitonic network stage by stage -- the reference's own algorithm) and with every granted core in the fast
+    mode, C2 in the fast mode.  About three seconds of CPU work."""
+    import water_sandbox_amd as ws
+    from oracle import oracle as O
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import oracle_from_params
+
+    rows = []
+    for cfg, mode, threads, steps in (("c1", O.SORT_EXACT, 1, 100), ("c1", O.SORT_FAST, O.default_threads(), 200),
+                                      ("c2", O.SORT_FAST, O.default_threads(), 20)):
+        O.set_threads(threads)
+        p, prm = ws.workloads.make_workload(cfg, "cloud")
+        orc = oracle_from_params(O, p, prm)
+        orc.step(mode)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            orc.step(mode)
+        dt = time.perf_counter() - t0
+        rows.append({"config": cfg, "particles": int(orc.n), "sort_mode": "exact (bitonic network)" if mode == O.SORT_EXACT else "fast (radix)",
+                     "cores": threads, "value": steps / dt, "unit": "steps/s", "sample": "%d steps after 1 warm-up, uniform cloud" % steps})
+    O.set_threads(O.default_threads())
+    return rows
 
 
 def load_traffic(config, dist, warmup, steps, kernel):
@@ -544,7 +572,8 @@ def main():
     north_star = None
     if not args.no_north_star and not distributed and cfg_name == "c3" and args.dist == "cloud" and not args.graph:
         npos, nparams = ws.workloads.make_workload("c4", "cloud")
-        w4 = ws.FluidWorker(npos, nparams, device=local_rank, profile=False)
+        w4 = ws.FluidWorker(npos, nparams, device=local_rank, profile=True)
+        w4.profile_select(neighbour_mask)
         w4.run(10)
         w4.sync()
         t0 = time.perf_counter()
@@ -553,11 +582,16 @@ def main():
         early = (time.perf_counter() - t0) / 20
         w4.run(SETTLED_FROM - 30)
         w4.sync()
+        w4.profile_reset()
         t0 = time.perf_counter()
         w4.run(SETTLED_STEPS)
         w4.sync()
         late = (time.perf_counter() - t0) / SETTLED_STEPS
+        ns_kernel_ms = {k: v[0] / max(v[1], 1) for k, v in w4.profile().items() if v[1]}
         w4.close()
+        # measured bytes at the north-star size: this round's committed counter passes of exactly this
+        # window (profiles/r05/traffic.json[c4-cloud-w400-k100]) over THIS run's step time
+        ns_traffic = step_traffic(load_window_counters("c4", "cloud", SETTLED_FROM, SETTLED_STEPS), late * 1e3)
         north_star = {"target": ">= 10 M particles at >= 60 steps/s on one MI355X (BASELINE.json north_star)",
                       "workload": "C4: %d particles, uniform cloud seed 0x%X, one GPU" % (npos.shape[0], ws.workloads.cloud_seed("c4")),
                       "particles": int(npos.shape[0]),
@@ -566,8 +600,58 @@ def main():
                       "early": {"window": "steps 10..30", "steps_per_s": 1.0 / early, "ms_per_step": early * 1e3},
                       "meets_10M_at_60": bool(npos.shape[0] >= 10_000_000 and 1.0 / late >= 60.0),
                       "algorithmic_GBps_step": B_ALG_STEP * npos.shape[0] / late / 1e9,
-                      "frac_of_measured_copy_bw_algorithmic": B_ALG_STEP * npos.shape[0] / late / 1e9 / HBM_COPY_GBS}
+                      "frac_of_measured_copy_bw_algorithmic": B_ALG_STEP * npos.shape[0] / late / 1e9 / HBM_COPY_GBS,
+                      "kernel_ms": ns_kernel_ms,
+                      "step_traffic": ns_traffic,
+                      "traffic_frac_of_measured_copy_bw": ns_traffic["frac_of_measured_copy_bw"] if ns_traffic else None,
+                      "meets_40_percent_of_measured_hbm_bandwidth": bool(ns_traffic and ns_traffic["frac_of_measured_copy_bw"] >= 0.4),
+                      "bandwidth_note": "north_star asks for >= 40 % of measured HBM bandwidth: the settled step is bound by VALU issue "
+                                        "and divergent gathers (DESIGN.md 5), so its counter-measured traffic stays far below that; "
+                                        "the early window of the same trajectory is the bandwidth-bound one"}
         del npos
+
+    # The reference's OWN configuration (src/fluid_compute.rs:15-17,:285: the 64 x 32 x 32 lattice, 65 536 particles -- the
+    # only N the real app runs): five launches of a few microseconds each, the launch-bound regime.
+    # Direct launches, the captured graph, and the frame pattern, steps 10..210 and 400..600 of the lattice's trajectory.
+    ref_config = None
+    if not args.no_north_star and not distributed and cfg_name == "c3" and args.dist == "cloud" and not args.graph:
+        rpos, rparams = ws.workloads.make_workload("ref", "lattice")
+
+        def ref_leg(graph):
+            w5 = ws.FluidWorker(rpos, rparams, device=local_rank, profile=False, graph=graph)
+            out5 = {}
+            done5 = 0
+            for label, start5 in (("early", 10), ("settled", SETTLED_FROM)):
+                w5.run(start5 - done5)
+                w5.sync()
+                t0 = time.perf_counter()
+                w5.run(200)
+                w5.sync()
+                out5[label] = (time.perf_counter() - t0) / 200 * 1e3
+                done5 = start5 + 200
+            if not graph:
+                w5.read_positions_begin_owned()
+                w5.read_positions_end()
+                w5.sync()
+                t0 = time.perf_counter()
+                for _ in range(200):
+                    w5.read_positions_begin_owned()
+                    w5.run(1)
+                    w5.read_positions_end()
+                w5.sync()
+                out5["frame"] = (time.perf_counter() - t0) / 200 * 1e3
+            w5.close()
+            return out5
+
+        direct, graphed = ref_leg(False), ref_leg(True)
+        ref_config = {"workload": "the reference's default: %d particles, cube_fluid(64, 32, 32) lattice, container 16 x 9 x 9" % rpos.shape[0],
+                      "particles": int(rpos.shape[0]),
+                      "ms_per_step": direct["early"], "steps_per_s": 1e3 / direct["early"], "window": "steps 10..210",
+                      "settled": {"window": "steps 400..600", "ms_per_step": direct["settled"], "steps_per_s": 1e3 / direct["settled"]},
+                      "graph_replay": {"ms_per_step": graphed["early"], "settled_ms_per_step": graphed["settled"],
+                                       "vs_direct": graphed["early"] / direct["early"], "vs_direct_settled": graphed["settled"] / direct["settled"]},
+                      "with_readback": {"ms_per_frame": direct["frame"], "window": "200 frames from step 600", "bytes_per_frame": int(rpos.shape[0]) * 12},
+                      "regime": "launch-bound: five dependent launches per step"}
 
     if rank == 0:
         global_steps_per_s = args.steps / elapsed
@@ -639,6 +723,8 @@ def main():
             out["with_readback"] = with_readback
         if north_star is not None:
             out["north_star"] = north_star
+        if ref_config is not None:
+            out["ref_config"] = ref_config
         if world > 1:
             # the like-for-like yard-stick of a multi-GPU run: the SAME configuration on one GPU (it fits: C5 is 27 GB),
             # from the committed one-GPU line of that configuration.  north_star's ">= 6x at 8 GPUs" is judged on
@@ -667,6 +753,8 @@ def main():
             out["config"]["grid_cells"] = grid
         if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(pos, params, args.cpu_steps)
+            if cfg_name == "c3":
+                out["cpu_baseline"]["other_configs"] = cpu_baseline_other_configs()
         else:
             out["cpu_baseline"] = None
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

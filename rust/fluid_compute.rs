@@ -64,7 +64,12 @@ extern "C" {
     fn ws_unpin_host_buffer(h: *mut WsHandle, ptr: *mut c_void) -> c_int;
     fn ws_reset(h: *mut WsHandle, pos_xyz: *const f32) -> c_int;
     fn ws_last_error(h: *mut WsHandle) -> *const c_char;
+    fn ws_abi_version() -> u32;
 }
+
+// include/wsfluid.h WS_ABI_VERSION as this file was written against it (2: round 5 -- ws_transport.struct_size, flags
+// 64 / 128 / 256).  A library of another version lays its structs out differently: refuse it at start-up.
+const WS_ABI_VERSION: u32 = 2;
 
 // ws_status values the shim tells apart (include/wsfluid.h)
 const WS_ERR_INVALID_ARG: c_int = 1;
@@ -188,6 +193,8 @@ impl Plugin for FluidComputePlugin {
         params.ext_max = ext.ext_max.to_array();
         let mut positions = flatten(&points);
         let mut handle: *mut WsHandle = std::ptr::null_mut();
+        let abi = unsafe { ws_abi_version() };
+        assert_eq!(abi, WS_ABI_VERSION, "libwsfluid.so speaks ABI version {abi}, this shim was written against {WS_ABI_VERSION}");
         let status = unsafe { ws_create(&params, positions.as_ptr(), points.len() as u32, std::ptr::null(), &mut handle) };
         check(std::ptr::null_mut(), status, "ws_create");
         // the readback target lives as long as the worker: page-lock it once (PCIe-rate copies)

@@ -275,3 +275,33 @@ def test_four_slabs_through_the_collapse_and_rebound_of_c2_match_the_single_hand
         assert st["migration_peak"] <= st["migration_capacity"] and st["halo_peak"] <= st["halo_capacity"]
         assert all(4096 <= x <= st["migration_capacity"] // 4 for x in sizes), sizes  # sized by the fluid, not the capacity
     assert sum(c["left"] for _, _, _, c in res) > 10000
+
+
+def test_slabs_created_with_different_flags_fail_alike_instead_of_hanging(ws):
+    """Every choice that fixes the step's collective sequence (message sizing, halo overlap, capture) must be the same on
+    every rank: ws_slab_create all-gathers a mode word and fails on ALL ranks when they differ (a rank that
+    differs used to issue its halos on the other communicator and the run hung inside the transport)."""
+    import threading
+
+    params = ws.make_params(container_size=(16.0, 9.0, 9.0))
+    pos = ws.workloads.uniform_cloud(16384, 11, list(params.ext_min), list(params.ext_max))
+    owner = ws.slab.assign(params, pos, 2)
+    hub = ws.slab.LoopbackHub(2)
+    seen = [None, None]
+
+    def body(r):
+        sel = np.flatnonzero(owner == r).astype(np.uint32)
+        try:
+            w = ws.slab.SlabWorker(pos[sel], sel, pos.shape[0], params, r, 2, hub.transport(r), overlap=(r == 0))
+            w.close()
+            seen[r] = "created"
+        except ws.WsError as e:
+            seen[r] = (e.status, str(e))
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r in range(2):
+        assert seen[r] != "created" and seen[r][0] == 1 and "different flags" in seen[r][1], seen  # WS_ERR_INVALID_ARG on both

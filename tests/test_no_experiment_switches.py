@@ -28,7 +28,8 @@ def test_product_sources_have_no_experiment_switches():
 
 # every environment hook the sources know (csrc/ws_devhooks.h: compiled in with -DWS_DEV_HOOKS only)
 DEV_HOOKS = ("WS_VARIANT", "WS_CELL_BUDGET", "WS_COPY_STREAM_PRIORITY", "WS_RCCL_LIBRARY", "WS_RCCL_SINGLE_COMM",
-             "WS_SLAB_EXACT_ONE_RANK", "WS_SLAB_FLOOR_MIGRATION", "WS_SLAB_FLOOR_FAR", "WS_SLAB_FLOOR_HALO", "WS_SLAB_COMM_PRIORITY")
+             "WS_SLAB_EXACT_ONE_RANK", "WS_SLAB_FLOOR_MIGRATION", "WS_SLAB_FLOOR_FAR", "WS_SLAB_FLOOR_HALO", "WS_SLAB_COMM_PRIORITY",
+             "WS_TILE_SCHEDULE", "WS_SCHED_CLASSES", "WS_SCHED_GROUP", "WS_FAIL_REGRID")
 
 
 def test_product_sources_read_the_environment_through_the_dev_hook_macro_only():

@@ -126,6 +126,19 @@ def test_status_constants_of_the_shim_match_the_header():
     assert 'check(h, unsafe { ws_set_params' not in body
 
 
+def test_the_shim_checks_the_abi_version_the_header_declares():
+    """the struct layouts changed under an unchanged version once.  The shim carries the version it was
+    written against, compares it with ws_abi_version() before anything crosses the boundary, and this test ties the
+    constant to the header."""
+    header = int(re.search(r"#define WS_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "wsfluid.h")).read()).group(1))
+    shim = int(re.search(r"const WS_ABI_VERSION: u32 = (\d+);", RUST).group(1))
+    assert shim == header
+    build = RUST[RUST.index("impl Plugin for FluidComputeWorkerPlugin") if "impl Plugin for FluidComputeWorkerPlugin" in RUST else 0:]
+    assert build.index("ws_abi_version()") < build.index("ws_create(&params")
+    hpp = open(os.path.join(ROOT, "water-sandbox_amd", "host", "fluid_compute.hpp")).read()
+    assert hpp.count("check_abi();") >= 2 and "ws_abi_version() != WS_ABI_VERSION" in hpp
+
+
 def test_header_parser_sees_every_declared_function(ws):
     assert sorted(c_prototypes()) == sorted(ws.fluid.ABI_SYMBOLS)
 

@@ -4,7 +4,7 @@
 # Everything lands under gpurun_out/r05/; what is judged is copied into profiles/r05/ afterwards by hand.
 set -o pipefail
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
-export TMPDIR=/tmp
+export TMPDIR=/tmp WS_NO_REBUILD=1
 R=r05
 out=gpurun_out/$R; mkdir -p $out
 job=$1; shift
@@ -53,6 +53,43 @@ chunk_trace)  # chunk_trace <cfg> <state step> <chunks> : kernel timeline of a f
   ;;
 wg_timeline)  # wg_timeline <cfg> <state step>
   python3 tools/wg_timeline.py "$@" 2>&1 | tee -a $out/wg_timeline.log
+  ;;
+sched_ab)  # sched_ab <cfg> <state step> <steps>
+  python3 tools/sched_ab.py "$@" 2>&1 | tee -a $out/sched_ab.log
+  ;;
+tcc)  # tcc <cfg> <warm> <steps> : L2 hit / miss counters of one window
+  tools/pmc.sh ${R}tcc$1w$2 $1 cloud $2 $3 t > $out/pmc_tcc_$1_w$2.log 2>&1
+  python3 - $1 $2 $3 <<'PY' | tee -a $out/tcc.log
+import collections, csv, glob, json, os, sys
+cfg, warm, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+f = max(glob.glob("gpurun_out/pmc_r05tcc%sw%d_t/*/*_counter_collection.csv" % (cfg, warm)), key=os.path.getmtime)
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    vals[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in vals.items():
+    if k.startswith("k_") and all(len(v) >= steps for v in cs.values()):
+        m = {c: sum(v[-steps:]) / steps for c, v in cs.items()}
+        m["hit_rate"] = m.get("TCC_HIT_sum", 0) / max(m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0), 1)
+        print(json.dumps({"config": cfg, "warmup": warm, "kernel": k, **{c: round(v, 3) for c, v in m.items()}}))
+PY
+  ;;
+slab_timeline)  # the two-slab C3x2 step under the kernel trace, communication stream at the highest / the default priority
+  mkdir -p $out/slab
+  for pr in highest default; do
+    rm -rf $out/slab/trace_$pr
+    if [ $pr = default ]; then export WS_SLAB_COMM_PRIORITY=default; else unset WS_SLAB_COMM_PRIORITY; fi
+    GPU_MAX_HW_QUEUES=24 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/slab/trace_$pr -- python3 tools/slab_timeline.py run 40 > $out/slab/run_$pr.log 2>&1 || { echo "run $pr failed"; tail -5 $out/slab/run_$pr.log; }
+    python3 tools/slab_timeline.py report $(ls $out/slab/trace_$pr/*/*_kernel_trace.csv | head -1) 40 > $out/slab/timeline_two_slabs_c3x2_$pr.json
+    python3 tools/step_timeline.py $(ls $out/slab/trace_$pr/*/*_kernel_trace.csv | head -1) 60 k_scan > $out/slab/step_timeline_$pr.txt 2>&1 || true
+    rm -rf $out/slab/trace_$pr
+  done
+  unset WS_SLAB_COMM_PRIORITY
+  cat $out/slab/timeline_two_slabs_c3x2_*.json
+  ;;
+fuzz_graph)  # fuzz_graph <cases> : violent random slab cases, captured multi-rank steps with fixed-capacity messages
+  mkdir -p $out/slab
+  WS_RCCL_LIBRARY=$GRAFT_REPO_ROOT/tests/libfakerccl.so GPU_MAX_HW_QUEUES=24 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 10 1000 python3 tools/slab_fuzz.py ${1:-100} 20261005 graph > $out/slab/slab_fuzz_graph_fixed_messages.log 2>&1
+  echo "fuzz exit $?"; tail -3 $out/slab/slab_fuzz_graph_fixed_messages.log
   ;;
 *)
   echo "unknown job $job"; exit 2

@@ -40,8 +40,15 @@ out = {"window": {"config": cfg, "dist": dist, "warmup": warm, "steps": steps, "
        "units": "bytes per launch, mean over the timed window",
        "read_resolved": read, "read_requests": {"32B": n32, "64B": n64, "128B": n128},
        "fetch_raw": fetch, "write_raw": write, "calibration": cal}
-force = "k_force_listed<false, false, false>"  # <IEEE, ACCEL_ONLY, CUT>: the step's launch, not the on-demand accel pass
-dens = "k_density_listed<false, false>"
+def step_kernel(prefix):
+    """The step's instantiation of a neighbour kernel, whatever its trailing template arguments are this round."""
+    hits = [k for k in read if k.startswith(prefix)]
+    assert len(hits) == 1, (prefix, hits)
+    return hits[0]
+
+
+force = step_kernel("k_force_listed<false, false, false")  # <IEEE, ACCEL_ONLY, CUT, ...>: the step's launch, not the on-demand accel pass
+dens = step_kernel("k_density_listed<false, false")
 out["bytes_per_launch"] = {"force_integrate_bin": read[force] + write[force], "density": read[dens] + write[dens]}
 out["bytes_per_launch_note"] = "size-resolved read requests (32 n32 + 64 n64 + 128 n128) + WRITE_SIZE"
 allt = json.load(open(out_path)) if os.path.exists(out_path) else {}

@@ -20,10 +20,15 @@ L = ws.fluid.bind_library(os.path.join(ROOT, "tools", "ab", "libwgt.so"))
 hip = C.CDLL("libamdhip64.so")
 pos, params = ws.workloads.make_workload(cfg, "cloud")
 n = pos.shape[0]
+# SCHED=0 | c<classes>g<particles per group> in the environment: the tile schedule of the kernels
+setting = os.environ.get("SCHED", "0")
+os.environ["WS_TILE_SCHEDULE"] = {"0": "0", "outliers": "2"}.get(setting, "1")
+if setting not in ("0", "outliers"):
+    os.environ["WS_SCHED_CLASSES"], os.environ["WS_SCHED_GROUP"] = setting[1:].split("g")
 w = ws.FluidWorker(pos, params, library=L)
 w.run(warm)
 w.sync()
-n4, n5 = (n + 63) // 64, (n + 127) // 128
+n4, n5 = 2 * ((n + 63) // 64) + 64, 2 * ((n + 127) // 128) + 64  # (a scheduled launch has up to 1.5 x the workgroups)
 buf = C.c_void_p()
 assert hip.hipMalloc(C.byref(buf), C.c_size_t(16 * (n4 + n5))) == 0
 hip.hipMemset(buf, 0, C.c_size_t(16 * (n4 + n5)))
@@ -50,12 +55,14 @@ for name, a, m in (("k_density_listed", 0, n4), ("k_force_listed", n4, n5)):
     inflight = [int(np.sum((s <= p) & (e > p))) for p in pts]
     # work left when the last workgroup starts: workgroup-microseconds after that moment
     rest = np.clip(e - np.maximum(s, last_dispatch), 0, None).sum()
-    out = {"kernel": name, "config": cfg, "state_step": warm, "workgroups": int(ok.sum()), "span_us": round(float(span), 1),
+    xcd = np.flatnonzero(ok) % 8
+    out = {"kernel": name, "config": cfg, "schedule": setting, "per_xcd_workgroups": [int(np.sum(xcd == x)) for x in range(8)], "state_step": warm, "workgroups": int(ok.sum()), "span_us": round(float(span), 1),
            "last_dispatch_us": round(float(last_dispatch), 1), "drain_us": round(float(span - last_dispatch), 1),
            "wg_duration_us": {k: round(float(np.percentile(dur, q)), 1) for k, q in (("p10", 10), ("p50", 50), ("p90", 90), ("p99", 99), ("max", 100))},
            "mean_wg_us": round(float(dur.mean()), 1),
            "in_flight_at_fraction_of_span": {("%.2f" % (p / span)): v for p, v in zip(pts, inflight)},
            "wg_us_after_last_dispatch": round(float(rest), 0),
            "busy_integral_over_peak": round(float(dur.sum() / (span * max(inflight))), 3),
-           "per_xcd_end_us": [round(float(e[np.arange(int(ok.sum())) % 8 == x].max()), 1) for x in range(8)]}
+           "per_xcd_end_us": [round(float(e[xcd == x].max()), 1) for x in range(8)],
+           "per_xcd_wg_us_sum": [round(float(dur[xcd == x].sum()), 0) for x in range(8)]}
     print(json.dumps(out))

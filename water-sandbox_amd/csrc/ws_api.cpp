@@ -200,6 +200,8 @@ void free_grid(ws_handle *h)
 ws_status alloc_grid(ws_handle *h)
 {
     const WsDev &d = h->dev;
+    // (developer builds: WS_FAIL_REGRID=1 makes a RE-grid's allocation fail -- the tests' way to a dead handle)
+    if (h->steps > 0 && WS_DEV_ENV("WS_FAIL_REGRID")) return fail(h, WS_ERR_OUT_OF_MEMORY, "cell tables: allocation failure forced by WS_FAIL_REGRID");
     if (h->grid_alloc_cells < d.ncells) {
         free_grid(h);
         HIP_TRY(h, hipMalloc(&h->count, (size_t)d.ncells * 4));
@@ -283,6 +285,16 @@ ws_status ensure_stage(ws_handle *h, size_t bytes)
     h->stage_bytes = bytes;
     return WS_OK;
 }
+
+// A handle whose re-grid failed after the old tables were given up (h->dead; ws_set_params, slab_regrid): its cell
+// tables, sorted arrays or -- on a slab -- its particle set are missing or half rebuilt.  EVERY entry point that would
+// launch over them, or enter a collective its peers may skip, refuses with the reason instead (only ws_step
+// did; a frame loop reads before it steps).  What still works: ws_destroy, ws_last_error, ws_ready, the profile and
+// statistics getters, and ws_read_positions_end / _view of a readback that had completed.
+#define WS_DEAD_CHECK(h)                                               \
+    do {                                                               \
+        if ((h)->dead) return fail((h), WS_ERR_HIP, (h)->err.c_str()); \
+    } while (0)
 
 // The test-only build also contains a validation mode that runs the reference's six passes literally
 // (tests/refcheck/): its handles are handed over at the top of every entry point.  Nothing of it exists in the product.
@@ -399,11 +411,93 @@ void bound_pending(ws_handle *h)
     if (hipStreamSynchronize(h->stream) == hipSuccess) drain_profile(h);
 }
 
+// The tile schedule of a single-GPU handle's K4 / K5 (WsSched, ws_internal.h): split / perm / cost per kernel in two
+// sets, a stream and two events for k_schedule.  Built once here with no costs known: equal shares, tiles in their own
+// order.  Only handles of WS_SCHED_MIN_PARTICLES .. WS_SCHED_MAX_PARTICLES particles take it (profiles/r05/sched/):
+//   * there (C2: 262 144 particles) a neighbour kernel is ONE round of workgroups -- the whole grid is resident at once
+//     -- so it lasts as long as its slowest workgroup lives, and starting the expensive tiles first is worth 20 % of
+//     both kernels (step -12 % settled, -10 % sparse);
+//   * below (the reference's own 65 536 particles, C1) the kernels gain 4-6 % but the step is launch-bound and the extra
+//     launch with its two cross-stream events costs 8 us of a 75 us step;
+//   * above (C3, C4) an XCD works through many rounds, the equal static shares are within 4 % of balanced, and every
+//     reordering of the tiles costs more in L2 locality than the shorter drain returns (K5 +4 ... +13 %).
+#define WS_SCHED_MIN_PARTICLES (1u << 17)
+#define WS_SCHED_MAX_PARTICLES (1u << 20)
+#define WS_SCHED_OUTLIERS_FROM (1u << 23)  // EXPERIMENT
+
+void free_schedule(ws_handle *h)
+{
+    if (h->sched_stream) {
+        hipStreamSynchronize(h->sched_stream);
+        hipStreamDestroy(h->sched_stream);
+    }
+    if (h->ev_sched_in) hipEventDestroy(h->ev_sched_in);
+    if (h->ev_sched_out) hipEventDestroy(h->ev_sched_out);
+    hipFree(h->sched4[0].cost);  // (shared by both of K4's sets)
+    for (int k = 0; k < 2; k++) {
+        hipFree(h->sched4[k].split); hipFree(h->sched4[k].perm);
+        hipFree(h->sched5[k].split); hipFree(h->sched5[k].perm); hipFree(h->sched5[k].cost);
+        h->sched4[k] = h->sched5[k] = WsSched{};
+    }
+    h->sched_stream = nullptr;
+    h->ev_sched_in = h->ev_sched_out = nullptr;
+    h->sched_on = false;
+}
+
+ws_status alloc_schedule(ws_handle *h)
+{
+    if (h->variant != WS_VARIANT_LISTED || h->slab) return WS_OK;
+    uint32_t min_n = WS_SCHED_MIN_PARTICLES, max_n = WS_SCHED_MAX_PARTICLES;
+    uint32_t outliers_from = WS_SCHED_OUTLIERS_FROM;
+    if (const char *v = WS_DEV_ENV("WS_TILE_SCHEDULE")) {  // developer builds: 0 = never, 1 = the classes at every size, 2 = the outlier mode at every size (A/B runs)
+        min_n = 0;
+        max_n = atoi(v) == 1 ? 0xFFFFFFFFu : 0u;
+        outliers_from = atoi(v) == 2 ? 0u : 0xFFFFFFFFu;
+    }
+    const bool classes = h->n <= max_n && h->n >= min_n, outliers = !classes && h->n >= outliers_from;
+    if (!classes && !outliers) return WS_OK;
+    if (outliers) {
+        h->sched_classes = 0;  // k_schedule: equal static shares, tiles that cost > 4 x the average first
+        h->sched_group = 1;
+    }
+    if (classes) {
+        if (const char *v = WS_DEV_ENV("WS_SCHED_CLASSES")) h->sched_classes = (uint32_t)atoi(v);
+        if (const char *v = WS_DEV_ENV("WS_SCHED_GROUP")) h->sched_group = (uint32_t)atoi(v);
+    }
+    h->sched_tiles4 = (h->n + wsk_density_tile() - 1u) / wsk_density_tile();
+    h->sched_tiles5 = (h->n + wsk_force_tile() - 1u) / wsk_force_tile();
+    uint32_t *cost4 = nullptr;
+    HIP_TRY(h, hipMalloc(&cost4, (size_t)h->sched_tiles4 * 4));
+    HIP_TRY(h, hipMemsetAsync(cost4, 0, (size_t)h->sched_tiles4 * 4, h->stream));
+    for (int k = 0; k < 2; k++) {
+        h->sched4[k].cost = cost4;
+        HIP_TRY(h, hipMalloc(&h->sched4[k].split, 16 * 4));
+        HIP_TRY(h, hipMalloc(&h->sched4[k].perm, (size_t)h->sched_tiles4 * 4));
+        HIP_TRY(h, hipMalloc(&h->sched5[k].split, 16 * 4));
+        HIP_TRY(h, hipMalloc(&h->sched5[k].perm, (size_t)h->sched_tiles5 * 4));
+        HIP_TRY(h, hipMalloc(&h->sched5[k].cost, (size_t)h->sched_tiles5 * 4));
+        HIP_TRY(h, hipMemsetAsync(h->sched5[k].cost, 0, (size_t)h->sched_tiles5 * 4, h->stream));
+    }
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->sched_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sched_in, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sched_out, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++)  // (costs all unknown: both sets come out as the equal shares)
+        wsk_schedule(h->stream, h->sched4[k], h->sched_tiles4, h->sched5[k], h->sched5[k], h->sched_tiles5, h->sched_classes, h->sched_group);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->sched_parity = 0;
+    h->sched_on = true;
+    return WS_OK;
+}
+
 // The single-GPU step: scan -> scatter -> reorder -> K4 -> K5+K6+K1'.  Enqueued directly or captured.
 void enqueue_step(ws_handle *h)
 {
     const WsDev &d = h->dev;
     hipStream_t s = h->stream;
+    // (not in a captured step: k_schedule joins the NEXT step, and the two sets alternate -- a replayed graph has one baked in)
+    const bool sched = h->sched_on && !h->alias && h->variant == WS_VARIANT_LISTED && !(h->flags & WS_FLAG_GRAPH);
+    const uint32_t par = h->sched_parity;
     {
         Prof p(h, WS_K_SCAN);
         // no fill cursors: particles are placed by the ranks they drew when they were binned
@@ -417,87 +511,30 @@ void enqueue_step(ws_handle *h)
         Prof p(h, WS_K_REORDER);
         wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
     }
+    if (sched) hipStreamWaitEvent(s, h->ev_sched_out, 0);  // (the previous step's k_schedule: long done; nothing before the first)
     {
         // one launch each: timed by events the launch itself carries (no event packets between the kernels)
         ProfLaunch p(h, WS_K_DENSITY);
         wsk_density(s, d, h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->ieee, h->stats, h->mask, h->sxyz,
-                    p.events());
+                    p.events(), sched ? h->sched4[par] : WsSched{});
+    }
+    if (sched) {
+        // next step's schedule, beside this step's K5 (16 workgroups; K5 is not bound by what they need): from the costs
+        // K4 has just measured and the ones the PREVIOUS step's K5 left in the other set
+        hipEventRecord(h->ev_sched_in, s);
+        hipStreamWaitEvent(h->sched_stream, h->ev_sched_in, 0);
+        wsk_schedule(h->sched_stream, h->sched4[par ^ 1u], h->sched_tiles4, h->sched5[par ^ 1u], h->sched5[par ^ 1u], h->sched_tiles5,
+                     h->sched_classes, h->sched_group);
+        hipEventRecord(h->ev_sched_out, h->sched_stream);
+        h->sched_parity = par ^ 1u;
     }
     {
         ProfLaunch p(h, WS_K_FORCE);
         wsk_force(s, d, h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->ieee, h->mask, false, p.events());
+                  h->variant, h->ieee, h->mask, false, p.events(), sched ? h->sched5[par] : WsSched{});
     }
     h->pred_stale = true;   // the epilogue stores position and velocity only (k_reorder)
     h->accel_stale = true;  // ... and no accelerations (refresh_accel)
-}
-
-// The chunked single-GPU step.  The sort phase is global; then the sorted order is cut into
-// `chunks` ranges of whole x cell layers (x is the slowest sort axis: a range of layers is a contiguous range of slots,
-// delimited by two cell starts the kernels read on the device) and K4(c) / K5(c) run on two streams of their own:
-//     stream A:  K4(0) K4(1) K4(2) ...                K5(c) needs the densities of layers +-1: K4(c - 1), K4(c), K4(c + 1)
-//     stream B:        wait K4(1): K5(0)  wait K4(2): K5(1) ...
-// so that the VALU-bound radius sweep of one chunk and the gather-bound force walk of another share the CUs.  Same
-// kernels, same visit order, same per-particle arithmetic: bit-identical to the unchunked step.  Every chunk has at
-// least two cell layers, so the wrapped stencil cells of a border row (ws_kernels.hip, WsCut) stay inside chunk c + 1.
-// K5's epilogue writes cur / cid_cur / rank in place; nothing reads them before the next step's k_place, which waits
-// for all of it on `stream`.
-void enqueue_step_chunked(ws_handle *h)
-{
-    const WsDev &d = h->dev;
-    hipStream_t s = h->stream;
-    const uint32_t C = std::max(1u, std::min(h->chunks, (uint32_t)d.dim[0] / (h->chunk_comb ? 8u : 2u)));  // (a re-grid may have left fewer layers)
-    wsk_scan(s, h->count, h->start + d.guard, nullptr, h->bsum, d.ncells, true, 0);
-    wsk_place(s, d, h->cid_cur, h->cur.rank, h->cur.pos, h->start, h->slot_tmp, h->id_tmp);
-    wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
-    hipEventRecord(h->chunk_ev[0], s);
-    const int mode = h->chunk_mode;  // 0: K4 on one stream, K5 on one; 1: K4 on one, K5 on two; 2: K4 on two, K5 on two
-    hipStream_t k4s[2] = {h->chunk_stream[0], mode >= 2 ? h->chunk_stream[1] : h->chunk_stream[0]};
-    hipStream_t k5s[2] = {h->chunk_stream[2], mode >= 1 ? h->chunk_stream[3] : h->chunk_stream[2]};
-    hipStreamWaitEvent(k4s[0], h->chunk_ev[0], 0);
-    if (k4s[1] != k4s[0]) hipStreamWaitEvent(k4s[1], h->chunk_ev[0], 0);
-    const uint32_t rowy = (uint32_t)(d.dim[1] * d.dim[2]), nx = (uint32_t)d.dim[0];
-    const bool comb = h->chunk_comb;
-    auto chunk_dev = [&](uint32_t c) {
-        WsDev dc = d;
-        if (comb) {
-            // chunk c = the c-th part of EVERY XCD's x-slab (even slabs ascending, odd slabs descending, so that the parts
-            // that meet at a slab boundary belong to the same chunk: the neighbours of chunk c lie in chunks c - 1 .. c + 1)
-            dc.chunk_on = 2;
-            for (uint32_t x = 0; x < 8; x++) {
-                const uint32_t s0 = (uint32_t)((uint64_t)x * nx / 8), s1 = (uint32_t)((uint64_t)(x + 1) * nx / 8), nl = s1 - s0;
-                const uint32_t cc = (x & 1u) ? C - 1u - c : c;
-                dc.seg_c0[x] = (uint32_t)d.guard + (s0 + (uint32_t)((uint64_t)cc * nl / C)) * rowy;
-                dc.seg_c1[x] = (uint32_t)d.guard + (s0 + (uint32_t)((uint64_t)(cc + 1) * nl / C)) * rowy;
-            }
-            dc.n = (uint32_t)std::min<double>(d.n, h->chunk_grid_frac * d.n / (8.0 * C) + 256.0);  // estimated length of one range
-            return dc;
-        }
-        dc.chunk_on = 1;
-        dc.chunk_c0 = (uint32_t)d.guard + (uint32_t)((uint64_t)c * nx / C) * rowy;
-        dc.chunk_c1 = (uint32_t)d.guard + (uint32_t)((uint64_t)(c + 1) * nx / C) * rowy;
-        if (const char *v = WS_DEV_ENV("WS_CHUNK_GRID_FRAC"))  // EXPERIMENT: launch bound as a fraction of N / C (no overflow handling yet)
-            dc.n = (uint32_t)std::min<double>(d.n, atof(v) * d.n / C + 4096.0);
-        return dc;
-    };
-    for (uint32_t c = 0; c < C; c++) {
-        wsk_density(k4s[c & 1], chunk_dev(c), h->start, h->cid_srt, h->srt, h->mult, h->alias, h->variant, h->ieee, h->stats, h->mask, h->sxyz);
-        hipEventRecord(h->chunk_ev[1 + c], k4s[c & 1]);
-    }
-    for (uint32_t c = 0; c < C; c++) {
-        hipStream_t sk = k5s[c & 1];
-        for (uint32_t q = c ? c - 1 : 0; q <= std::min(c + 1, C - 1); q++) hipStreamWaitEvent(sk, h->chunk_ev[1 + q], 0);
-        wsk_force(sk, chunk_dev(c), h->start, h->cid_srt, h->srt, h->cur, h->accel, h->cid_cur, h->count, h->mult, h->alias,
-                  h->variant, h->ieee, h->mask, false);
-    }
-    hipEventRecord(h->chunk_ev[C + 1], k5s[0]);
-    hipStreamWaitEvent(s, h->chunk_ev[C + 1], 0);
-    if (k5s[1] != k5s[0]) {
-        hipEventRecord(h->chunk_ev[C + 2], k5s[1]);
-        hipStreamWaitEvent(s, h->chunk_ev[C + 2], 0);
-    }
-    h->pred_stale = true;
-    h->accel_stale = true;
 }
 
 // cur.pred is not maintained by the step loop (k_reorder recomputes it): bring it up to date for a reader off the loop
@@ -606,13 +643,7 @@ void free_all(ws_handle *h)
         hipStreamSynchronize(h->copy_stream);
         hipStreamDestroy(h->copy_stream);
     }
-    for (hipStream_t cs : h->chunk_stream)
-        if (cs) {
-            hipStreamSynchronize(cs);
-            hipStreamDestroy(cs);
-        }
-    for (hipEvent_t e : h->chunk_ev)
-        if (e) hipEventDestroy(e);
+    free_schedule(h);
     if (h->rb_gathered) hipEventDestroy(h->rb_gathered);
     if (h->rb_done) hipEventDestroy(h->rb_done);
     hipFree(h->rb_stage);
@@ -829,23 +860,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_TRY(alloc_grid(h));
     CREATE_TRY(upload_mult(h));
     CREATE_TRY(upload_positions(h, pos_xyz));
-    if (const char *v = WS_DEV_ENV("WS_CHUNKS")) {
-        h->chunks = (uint32_t)std::max(1, std::min(atoi(v), h->dev.dim[0] / 2));
-        if (h->chunks > 1) {
-            // K4's streams at the highest priority: the producer runs ahead, and streams of another priority never
-            // share a hardware queue with the step's and K5's streams (queues are pooled per priority)
-            int lo = 0, hi = 0;
-            CREATE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            const bool flat = WS_DEV_ENV("WS_CHUNK_FLAT_PRIORITY") != nullptr;
-            for (int k = 0; k < 4; k++)
-                CREATE_HIP(hipStreamCreateWithPriority(&h->chunk_stream[k], hipStreamNonBlocking, (k < 2 && !flat) ? hi : 0));
-            if (const char *m = WS_DEV_ENV("WS_CHUNK_MODE")) h->chunk_mode = atoi(m);
-            if (const char *m = WS_DEV_ENV("WS_CHUNK_COMB")) h->chunk_comb = atoi(m) != 0;
-            if (const char *m = WS_DEV_ENV("WS_CHUNK_GRID_FRAC")) h->chunk_grid_frac = atof(m);
-            h->chunk_ev.resize(h->chunks + 3, nullptr);
-            for (hipEvent_t &e : h->chunk_ev) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-    }
+    CREATE_TRY(alloc_schedule(h));
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = h;
@@ -912,8 +927,7 @@ ws_status ws_step(ws_handle *h)
             return WS_OK;
         }
     }
-    if (h->chunks > 1 && h->pred_stale && !h->alias && h->variant == WS_VARIANT_LISTED) enqueue_step_chunked(h);
-    else enqueue_step(h);
+    enqueue_step(h);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->done, s));
     h->done_recorded = true;
@@ -941,6 +955,7 @@ ws_status ws_ready(ws_handle *h, int *ready)
 ws_status ws_sync(ws_handle *h)
 {
     if (!h) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) {  // also the communication stream, and the device-side error bits of every rank seen so far
         const ws_status st = slab_settle(h);
@@ -955,6 +970,7 @@ ws_status ws_sync(ws_handle *h)
 ws_status ws_set_params(ws_handle *h, const ws_params *params)
 {
     if (!h) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     ws_status st = validate_params(h, params);
     if (st) return st;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1015,6 +1031,7 @@ ws_status ws_set_params(ws_handle *h, const ws_params *params)
 ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 {
     if (!h || (!out_xyz && !h->slab)) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_read_by_id(h, WS_PACK_POS_H, out_xyz);  // collective: all n_global positions, by id
     WS_REF_DISPATCH(h, ref_read_positions(h, out_xyz));
@@ -1036,6 +1053,7 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
 ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
 {
     if (!h) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     WS_REF_DISPATCH(h, fail(h, WS_ERR_UNSUPPORTED, "no asynchronous readback in the reference-order validation mode"));
     if (h->rb_inflight) return fail(h, WS_ERR_INVALID_ARG, "a readback is already in flight (call ws_read_positions_end)");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1126,6 +1144,7 @@ ws_status ws_read_positions_view(ws_handle *h, const float **out_xyz)
 ws_status ws_read_speeds(ws_handle *h, float *out_speed)
 {
     if (!h || (!out_speed && !h->slab)) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_read_by_id(h, WS_PACK_SPEED_H, out_speed);
     WS_REF_DISPATCH(h, ref_read_speeds(h, out_speed));
@@ -1163,6 +1182,7 @@ ws_status ws_unpin_host_buffer(ws_handle *h, void *ptr)
 ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
 {
     if (!h || (!out && !h->slab)) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_read_by_id(h, WS_PACK_RECORD_H, out);  // collective: all n_global records, by id
     WS_REF_DISPATCH(h, ref_read_particles(h, out));
@@ -1183,6 +1203,7 @@ ws_status ws_read_particles(ws_handle *h, ws_particle80 *out)
 ws_status ws_reset(ws_handle *h, const float *pos_xyz)
 {
     if (!h || !pos_xyz) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_reset(h, pos_xyz);  // pos_xyz: ALL n_global positions, on every rank
     WS_REF_DISPATCH(h, ref_upload_positions(h, pos_xyz));
@@ -1192,6 +1213,7 @@ ws_status ws_reset(ws_handle *h, const float *pos_xyz)
 ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
 {
     if (!h || !in) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->slab) return slab_write_particles(h, in);  // in: ALL n_global records, on every rank
     WS_REF_DISPATCH(h, ref_load(h, in, false));  // write_slice("particles") leaves the index buffers alone
@@ -1216,6 +1238,7 @@ ws_status ws_write_particles(ws_handle *h, const ws_particle80 *in)
 ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, uint32_t *cell_offsets)
 {
     if (!h) return WS_ERR_INVALID_ARG;
+    WS_DEAD_CHECK(h);
     HIP_TRY(h, hipSetDevice(h->device));
     // a slab handle answers for the WHOLE domain (collective: the keys of every rank's particles are gathered by id)
     const uint32_t n = h->slab ? h->slab->n_global : h->n;

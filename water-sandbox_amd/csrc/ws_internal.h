@@ -61,12 +61,6 @@ struct WsDev {
     uint32_t has_left, has_right;  // x-neighbours present
     uint32_t lidx[4];              // cell-start indices: layer 1 begin / end, layer nxl-2 begin / end
     const WsMig *mig;              // device copy; non-null = the force epilogue also does migration part 1
-    // A launch that covers ONE x-chunk of a single-GPU handle's sorted order (the chunked step: enqueue_step_chunked):
-    // the particles of the cell layers whose cell starts are start[chunk_c0] .. start[chunk_c1] (indices into the table
-    // INCLUDING its guard).  chunk_on == 0: the whole range.
-    uint32_t chunk_on, chunk_c0, chunk_c1;
-    // chunk_on == 2 ("comb"): eight ranges, one per XCD (workgroup b works for XCD b & 7): start[seg_c0[x]] .. start[seg_c1[x]]
-    uint32_t seg_c0[8], seg_c1[8];
     uint32_t mig_limit;            // records the NEXT step's migration messages will carry (<= WsMig::mig_cap; 0 = all of it)
     uint32_t far_limit;            // ... and each of its far messages (<= WsMig::far_cap; 0 = all of it)
 };
@@ -159,6 +153,19 @@ struct WsXYZ {
     float *x = nullptr, *y = nullptr, *z = nullptr;
 };
 
+// Tile schedule of a full-range launch of K4 / K5 (single-GPU handles).  Workgroup b works for XCD b & 7 (the hardware
+// deals workgroups round-robin over the XCDs) and takes the (b >> 3)-th entry of that XCD's part of `perm`:
+// perm[split[x] .. split[x + 1]) = the tiles of one contiguous x-slab of the sorted order (so an XCD's L2 keeps seeing one
+// neighbourhood), slabs cut so that every XCD gets the same COST, tiles inside a slab in descending cost classes (the
+// launch drains through its cheapest tiles, not through whichever came last).  cost[tile] = how long the tile's
+// workgroup ran in the previous step (100 MHz ticks), written by the kernels themselves; k_schedule turns it into
+// split / perm beside the next step's sort phase.  Any schedule computes the same results.
+struct WsSched {
+    uint32_t *split = nullptr;  // 9 words
+    uint32_t *perm = nullptr;   // ntiles words
+    uint32_t *cost = nullptr;   // ntiles words
+};
+
 struct WsEventPair {
     uint32_t kernel;
     hipEvent_t a, b;
@@ -229,13 +236,16 @@ struct ws_handle {
     WsRef ref;
 #endif
 
-    // The chunked step (single-GPU handles): K4 / K5 of different x-chunks side by side on two more streams
-    uint32_t chunks = 1;                   // 1 = the five launches one after another on `stream`
-    int chunk_mode = 2;
-    bool chunk_comb = false;
-    double chunk_grid_frac = 1.6;
-    hipStream_t chunk_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // K4 even / odd chunks, K5 even / odd chunks
-    std::vector<hipEvent_t> chunk_ev;      // [0] sorted, [1 .. chunks] K4(c) done, [chunks + 1], [chunks + 2] the K5 streams' ends
+    // Cost-guided tile schedule of the two neighbour kernels (single-GPU handles; ws_kernels.hip "tile schedule").
+    // Two sets: step t's kernels read set t & 1 while k_schedule, running beside K5(t) on a stream of its own, writes
+    // set (t + 1) & 1 from K4(t)'s costs and K5(t - 1)'s.
+    WsSched sched4[2], sched5[2];          // K4's (64-particle tiles) and K5's (128-particle tiles); cost4 is shared
+    uint32_t sched_tiles4 = 0, sched_tiles5 = 0;
+    bool sched_on = false;                 // the schedule arrays exist and describe the current particle count
+    uint32_t sched_classes = 8, sched_group = 64;  // cost classes; particles per group of tiles that is classed as one
+    uint32_t sched_parity = 0;             // the set the NEXT step's kernels read
+    hipStream_t sched_stream = nullptr;
+    hipEvent_t ev_sched_in = nullptr, ev_sched_out = nullptr;
 
     // WS_FLAG_GRAPH on a single-GPU handle: the captured steady-state step
     hipGraphExec_t graph_exec = nullptr;
@@ -311,6 +321,9 @@ struct WsSlab {
     uint32_t *cnt_send = nullptr, *cnt_all = nullptr;
     uint32_t *g_send = nullptr, *g_all = nullptr, *g_out = nullptr;
     size_t g_send_bytes = 0, g_all_bytes = 0, g_out_bytes = 0;
+    uint32_t *hist_dev = nullptr;     // x-layer histogram of a re-grid (one buffer, grown by doubling)
+    uint32_t hist_cap = 0;
+    uint32_t *agree_send = nullptr, *agree_all = nullptr;  // one word per rank: verdicts and the mode word (slab_agree_words)
     std::vector<uint32_t *> retired;  // outgrown gather buffers (freed with the handle: ws_slab.inc slab_grow)
     std::vector<uint32_t> counts;     // owned particles per rank as of the last gather
     std::vector<uint32_t> caps;       // ... and every rank's owned capacity (a re-grid decides for all ranks alike)
@@ -353,11 +366,17 @@ void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const 
 void wsk_refresh_pred(hipStream_t s, const WsDev &d, WsSoA cur);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz,
-                 const WsEventPair *ev = nullptr);
+                 const WsEventPair *ev = nullptr, WsSched sched = WsSched{});
+uint32_t wsk_density_tile(void);  // particles per tile of the listed K4 / K5
+uint32_t wsk_force_tile(void);
+uint32_t wsk_sched_grid(uint32_t ntiles);  // workgroups of a scheduled launch over ntiles tiles
+// s5_costs: the set whose cost array holds the K5 costs to schedule from (the set being written is read by nobody)
+void wsk_schedule(hipStream_t s, WsSched s4, uint32_t ntiles4, WsSched s5, WsSched s5_costs, uint32_t ntiles5, uint32_t nclasses,
+                  uint32_t group_particles);
 uint32_t wsk_mask_words(void);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
-               WsMask mask, bool accel_only, const WsEventPair *ev = nullptr);
+               WsMask mask, bool accel_only, const WsEventPair *ev = nullptr, WsSched sched = WsSched{});
 void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
 void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,

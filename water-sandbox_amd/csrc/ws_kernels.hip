@@ -98,13 +98,7 @@ struct WsSpan {
 __device__ __forceinline__ WsSpan ws_span(const WsDev &d, const uint32_t *__restrict__ start)
 {
     WsSpan sp = {d.base, d.n, 0xFFFFFFFFu, 0u};
-    if (!d.dyn) {
-        if (d.chunk_on) {  // one x-chunk of a single-GPU handle: a contiguous range between two cell starts
-            sp.lo = start[d.chunk_c0];
-            sp.len = start[d.chunk_c1] - sp.lo;
-        }
-        return sp;
-    }
+    if (!d.dyn) return sp;
     const uint32_t n = d.dyn[DY_N], end = d.base + n;
     sp.len = n;
     if (d.range_sel == WS_RANGE_ALL) return sp;
@@ -1093,27 +1087,25 @@ __device__ __forceinline__ void nd_tile(const WsDev &d, const uint32_t *__restri
     }
 }
 
-// COMB = false: the whole range, or the span a slab launch names (ws_span); tiles dealt XCD-contiguously.
-// COMB = true: one chunk of the chunked single-GPU step -- eight ranges of the sorted order, one per XCD (the XCD keeps
-// its x-slab of the domain over all chunks: its L2 sees the same neighbourhood the unchunked launch shows it); workgroup b
-// works for XCD b & 7 and takes that range's tiles (b >> 3), (b >> 3) + gridDim.x / 8, ... : the grid is sized from an
-// ESTIMATE of the ranges' lengths (they are known on the device only), the loop covers whatever they really are.
-template <bool IEEE, bool CUT, bool COMB>
+// SCHED = false: the whole range, or the span a slab launch names (ws_span); tiles dealt XCD-contiguously in equal shares.
+// SCHED = true (full-range launches of a single-GPU handle): the cost-guided tile schedule (WsSched, ws_internal.h);
+// the workgroup also measures how long its tile took -- next step's cost.
+template <bool IEEE, bool CUT, bool SCHED>
 __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t *__restrict__ start,
                                                          const uint32_t *__restrict__ cid_srt, WsSorted srt, WsXYZ sxyz,
-                                                         WsMask mask, uint32_t *__restrict__ stats)
+                                                         WsMask mask, uint32_t *__restrict__ stats, WsSched sched)
 {
     __shared__ float list[ND_ROWS * ND_P];  // d2 of the accepted candidates
-    if constexpr (COMB) {
-        const uint32_t x = blockIdx.x & 7u;
-        const uint32_t lo = start[d.seg_c0[x]], len = start[d.seg_c1[x]] - lo;
-        for (uint32_t j = blockIdx.x >> 3; j * ND_P < len; j += gridDim.x >> 3) {
-            uint32_t tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));  // nothing that depends on the lane is carried around the loop (registers)
-            const uint32_t v = j * ND_P + tid;
-            const bool valid = v < len;
-            nd_tile<IEEE, CUT>(d, start, cid_srt, srt, sxyz, mask, stats, list, lo + (valid ? v : len - 1u), valid, tid);
-        }
+    if constexpr (SCHED) {
+        const unsigned long long t0 = wall_clock64();
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const uint32_t s0 = sched.split[x], s1 = sched.split[x + 1];
+        if (j >= s1 - s0) return;
+        const uint32_t tile = sched.perm[s0 + j];
+        const uint32_t v = tile * ND_P + threadIdx.x;
+        const bool valid = v < d.n;
+        nd_tile<IEEE, CUT>(d, start, cid_srt, srt, sxyz, mask, stats, list, d.base + (valid ? v : d.n - 1u), valid, threadIdx.x);
+        if (threadIdx.x == 0) sched.cost[tile] = (uint32_t)min(wall_clock64() - t0, 0xFFFFFFull) + 1u;
     } else {
         const WsSpan sp = ws_span(d, start);
         const uint32_t ntiles = (sp.len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
@@ -1278,26 +1270,27 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
     if (valid) force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
 }
 
-// (COMB: see k_density_listed)
-template <bool IEEE, bool ACCEL_ONLY, bool CUT, bool COMB>
+// (SCHED: see k_density_listed)
+template <bool IEEE, bool ACCEL_ONLY, bool CUT, bool SCHED>
 __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                       uint32_t *__restrict__ count, WsMask mask)
+                                                       uint32_t *__restrict__ count, WsMask mask, WsSched sched)
 {
     __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
     __shared__ uint32_t t_delta[9 * NF_P];
-    if constexpr (COMB) {
-        const uint32_t x = blockIdx.x & 7u;
-        const uint32_t lo = start[d.seg_c0[x]], len = start[d.seg_c1[x]] - lo;
-        for (uint32_t j = blockIdx.x >> 3; j * NF_P < len; j += gridDim.x >> 3) {
-            uint32_t tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));  // nothing that depends on the lane is carried around the loop (registers)
-            const uint32_t v = j * NF_P + tid;
-            const bool valid = v < len;
-            nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
-                                           lo + (valid ? v : len - 1u), valid, tid);
-        }
+    if constexpr (SCHED) {
+        const unsigned long long t0 = wall_clock64();
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        const uint32_t s0 = sched.split[x], s1 = sched.split[x + 1];
+        if (j >= s1 - s0) return;
+        const uint32_t tile = sched.perm[s0 + j];
+        const uint32_t v = tile * NF_P + threadIdx.x;
+        const bool valid = v < d.n;
+        nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
+                                       d.base + (valid ? v : d.n - 1u), valid, threadIdx.x);
+        __syncthreads();  // (both waves of the tile are done)
+        if (threadIdx.x == 0) sched.cost[tile] = (uint32_t)min(wall_clock64() - t0, 0xFFFFFFull) + 1u;
     } else {
         const WsSpan sp = ws_span(d, start);
         const uint32_t ntiles = (sp.len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
@@ -1320,27 +1313,32 @@ uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
         else hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);                                    \
     } while (0)
 
+// workgroups of a scheduled launch: eight XCDs x the longest part of `perm` k_schedule ever gives one of them
+uint32_t wsk_sched_grid(uint32_t ntiles) { return 8u * (ntiles / 8u + ntiles / 16u + 2u); }
+uint32_t wsk_density_tile(void) { return ND_P; }
+uint32_t wsk_force_tile(void) { return NF_P; }
+
 template <bool IEEE>
 static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                            const uint8_t *mult, bool alias, int variant, uint32_t *stats, WsMask mask, WsXYZ sxyz,
-                           const WsEventPair *ev)
+                           const WsEventPair *ev, WsSched sched)
 {
     if (alias)
         WS_LAUNCH((k_density_simple<true, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
     else if (variant == WS_VARIANT_SIMPLE)
         WS_LAUNCH((k_density_simple<false, IEEE>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt, srt, mult);
     else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
-        WS_LAUNCH((k_density_listed<IEEE, true, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
-    else if (d.chunk_on == 2)  // d.n = the estimated length of ONE of the eight ranges
-        WS_LAUNCH((k_density_listed<IEEE, false, true>), dim3(8u * cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
+        WS_LAUNCH((k_density_listed<IEEE, true, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats, sched);
+    else if (sched.perm && !d.dyn)
+        WS_LAUNCH((k_density_listed<IEEE, false, true>), dim3(wsk_sched_grid(cdiv(d.n, ND_P))), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats, sched);
     else
-        WS_LAUNCH((k_density_listed<IEEE, false, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats);
+        WS_LAUNCH((k_density_listed<IEEE, false, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats, sched);
 }
 
 template <bool IEEE, bool ACCEL_ONLY>
 static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                          WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias,
-                         int variant, WsMask mask, const WsEventPair *ev)
+                         int variant, WsMask mask, const WsEventPair *ev, WsSched sched)
 {
     if (alias)
         WS_LAUNCH((k_force_simple<true, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt,
@@ -1350,35 +1348,218 @@ static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, c
                   srt, out, accel, cid_out, count, mult);
     else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
         WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, true, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
-                  accel, cid_out, count, mask);
-    else if (d.chunk_on == 2)  // d.n = the estimated length of ONE of the eight ranges
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, true>), dim3(8u * cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
-                  accel, cid_out, count, mask);
+                  accel, cid_out, count, mask, sched);
+    else if (sched.perm && !d.dyn)
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, true>), dim3(wsk_sched_grid(cdiv(d.n, NF_P))), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask, sched);
     else
         WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
-                  accel, cid_out, count, mask);
+                  accel, cid_out, count, mask, sched);
 }
 
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz,
-                 const WsEventPair *ev)
+                 const WsEventPair *ev, WsSched sched)
 {
-    if (ieee) launch_density<true>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev);
-    else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev);
+    if (ieee) launch_density<true>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev, sched);
+    else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev, sched);
 }
 
 // accel_only: nothing but accel[i] is written (see force_store_integrate_bin) -- the on-demand pass of the record views
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
-               WsMask mask, bool accel_only, const WsEventPair *ev)
+               WsMask mask, bool accel_only, const WsEventPair *ev, WsSched sched)
 {
     if (accel_only) {
-        if (ieee) launch_force<true, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
-        else launch_force<false, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
+        if (ieee) launch_force<true, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev, sched);
+        else launch_force<false, true>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev, sched);
     } else {
-        if (ieee) launch_force<true, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
-        else launch_force<false, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev);
+        if (ieee) launch_force<true, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev, sched);
+        else launch_force<false, false>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mult, alias, variant, mask, ev, sched);
     }
+}
+
+// ---------------------------------------------------------------------------------
+// tile schedule (WsSched, ws_internal.h): from the costs the neighbour kernels measured in the previous step to
+// split / perm for this one.  16 workgroups: workgroup (kernel k, XCD x) builds XCD x's part of kernel k's perm.
+// Every workgroup first derives the same eight cut points from the whole cost array (cheap: 4 B per tile from L2, and
+// no workgroup has to wait for another); the cuts give every XCD the same summed cost in one contiguous range of
+// tiles, within [1/2, 3/2] of an equal share of the tiles (the launch grid is sized for 3/2).  Inside its range a
+// workgroup orders the tiles by eight cost classes, heaviest first, tile order kept inside a class (a stable counting
+// sort made of block scans: no atomics).  A tile that has no cost yet counts as average.
+// ---------------------------------------------------------------------------------
+#define WS_SCHED_BLOCK 1024
+#define WS_SCHED_CLASSES 8
+
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s_w, uint32_t &total)
+{
+    // exclusive scan over the 1024 threads of the block; s_w: 16 words of LDS; two barriers
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    __syncthreads();  // (s_w may still be read from an earlier call)
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WS_SCHED_BLOCK / 64; w++) {
+        const uint32_t x = s_w[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    total = tot;
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_t nt4, WsSched s5, uint32_t nt5, uint32_t nclasses,
+                                                             uint32_t group_particles)
+{
+    __shared__ uint32_t s_w[WS_SCHED_BLOCK / 64];
+    __shared__ uint32_t s_cut[9];
+    __shared__ uint32_t s_max;
+    const bool second = blockIdx.x >= 8u;
+    const WsSched sc = second ? s5 : s4;
+    const uint32_t T = second ? nt5 : nt4, x = blockIdx.x & 7u, tid = threadIdx.x;
+    if (T == 0u) return;
+    // tiles are classed in GROUPS of neighbours in the sorted order (a group = about one row of cells): a class is a set
+    // of whole groups, so the tiles that run side by side still come from one neighbourhood
+    const uint32_t G = max(group_particles / (second ? (uint32_t)NF_P : (uint32_t)ND_P), 1u);
+    // ---- the cuts: tile ranges of equal summed cost
+    const uint32_t per = (T + WS_SCHED_BLOCK - 1u) / WS_SCHED_BLOCK;
+    const uint32_t a = min(tid * per, T), b = min(a + per, T);
+    uint32_t known = 0, sum = 0;
+    for (uint32_t t = a; t < b; t++) {
+        const uint32_t c = sc.cost[t];
+        known += c ? 1u : 0u;
+        sum += c;
+    }
+    uint32_t tot_known, tot_sum;
+    block_excl_scan_1024(known, s_w, tot_known);
+    block_excl_scan_1024(sum >> 10, s_w, tot_sum);  // (scaled: 2^20 tiles x 2^24 ticks do not fit 32 bits)
+    const uint32_t fill = tot_known ? (uint32_t)min(max(((unsigned long long)tot_sum << 10) / tot_known, 1ull), 0xFFFFFFull) : 1u;  // an unmeasured tile counts as average
+    // prefix of the FILLED costs (64-bit: 2^20 tiles x 2^24 ticks)
+    unsigned long long mine = 0;
+    for (uint32_t t = a; t < b; t++) {
+        const uint32_t c = sc.cost[t];
+        mine += c ? c : fill;
+    }
+    // 64-bit block scan as two 32-bit halves would need carries: costs are clamped to 2^24 and a thread sums at most
+    // `per` <= 2^10 tiles of them, so scale the per-thread sums down to 32 bits instead (the cuts need no more precision)
+    const uint32_t shift = 10u;
+    const uint32_t mine_s = (uint32_t)(mine >> shift);
+    uint32_t total_s;
+    const uint32_t before_s = block_excl_scan_1024(mine_s, s_w, total_s);
+    if (tid < 9u) s_cut[tid] = tid == 8u ? T : 0u;
+    __syncthreads();
+    const bool outliers_only = nclasses == 0u;  // large handles: equal static shares, only the outliers go first (below)
+    if (total_s >= 8u && !outliers_only) {
+        // the thread whose tiles contain the k-th eighth of the total looks for the exact tile
+        for (uint32_t k = 1; k < 8u; k++) {
+            const unsigned long long target = (unsigned long long)total_s * k / 8u;
+            if (target >= before_s && target < (unsigned long long)before_s + mine_s) {
+                unsigned long long run = (unsigned long long)before_s << shift;
+                const unsigned long long want = target << shift;
+                uint32_t t = a;
+                for (; t < b; t++) {
+                    const uint32_t c = sc.cost[t];
+                    run += c ? c : fill;
+                    if (run > want) break;
+                }
+                s_cut[k] = min(t + 1u, T);
+            }
+        }
+    } else if (tid == 0u) {
+        for (uint32_t k = 1; k < 8u; k++) s_cut[k] = (uint32_t)((unsigned long long)T * k / 8u);
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        // every XCD keeps between half and three halves of an equal share of the tiles (wsk_sched_grid), and the rest
+        // must stay coverable by the XCDs still to come
+        const uint32_t nmax = T / 8u + T / 16u + 1u, nmin = T / 16u;
+        uint32_t prev = 0;
+        for (uint32_t k = 1; k < 8u; k++) {
+            const uint32_t left = 8u - k;  // XCDs after this cut
+            uint32_t lo = prev + nmin, hi = prev + nmax;
+            lo = max(lo, T > left * nmax ? T - left * nmax : 0u);
+            hi = min(hi, T - min(T, left * nmin));
+            uint32_t c = s_cut[k];
+            c = min(max(c, lo), max(hi, lo));
+            c = min(c, T);
+            s_cut[k] = c;
+            prev = c;
+        }
+        s_cut[0] = 0u;
+        s_cut[8] = T;
+        s_max = 0u;
+    }
+    __syncthreads();
+    if (x == 0u && tid < 9u) sc.split[tid] = s_cut[tid];
+    // ---- this XCD's part of perm: descending cost classes
+    const uint32_t r0 = s_cut[x], r1 = s_cut[x + 1u], n = r1 - r0;
+    if (n == 0u) return;
+    // a thread owns whole groups: ceil(groups of the range / 1024) of them
+    const uint32_t g0 = r0 / G, g1 = (r1 + G - 1u) / G, ng = g1 - g0;
+    const uint32_t gper = (ng + WS_SCHED_BLOCK - 1u) / WS_SCHED_BLOCK;
+    const uint32_t ga = g0 + min(tid * gper, ng), gb = min(ga + gper, g1);
+    auto group_cost = [&](uint32_t g) {  // mean filled cost of the group's tiles that lie in this range
+        const uint32_t ta = max(g * G, r0), tb = min((g + 1u) * G, r1);
+        unsigned long long sumc = 0;
+        for (uint32_t t = ta; t < tb; t++) {
+            const uint32_t c = sc.cost[t];
+            sumc += c ? c : fill;
+        }
+        return tb > ta ? (uint32_t)(sumc / (tb - ta)) : 0u;
+    };
+    uint32_t mx = 0;
+    for (uint32_t g = ga; g < gb; g++) mx = max(mx, group_cost(g));
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sh, 64));
+    if ((tid & 63u) == 0u) atomicMax(&s_max, mx);
+    __syncthreads();
+    const uint32_t cmax = s_max + 1u;
+    // Outlier mode (handles above WS_SCHED_MAX_PARTICLES): class 0 = the tiles that cost more than four times the
+    // average -- a workgroup with a mask-overflow particle lives 0.8 ... 2.6 ms in the settled tall containers, where the
+    // average lives 0.12 ms, and a launch that starts such a tile late drains through it alone -- and class 1 = everybody
+    // else, in the sorted order's own sequence: the L2 locality of the static shares is untouched.
+    auto cls_of = [&](uint32_t v) {  // 0 = the heaviest part of the cost range
+        if (outliers_only) return v > 4u * fill ? 0u : 1u;
+        return (uint32_t)(((unsigned long long)(cmax - 1u - min(v, cmax - 1u)) * nclasses) / cmax);
+    };
+    uint32_t cnt[WS_SCHED_CLASSES];
+#pragma unroll
+    for (int k = 0; k < WS_SCHED_CLASSES; k++) cnt[k] = 0u;
+    for (uint32_t g = ga; g < gb; g++) {
+        const uint32_t k = cls_of(group_cost(g));
+        const uint32_t m = min((g + 1u) * G, r1) - max(g * G, r0);
+#pragma unroll
+        for (int q = 0; q < WS_SCHED_CLASSES; q++) cnt[q] += (k == (uint32_t)q) ? m : 0u;
+    }
+    uint32_t off[WS_SCHED_CLASSES], cbase = 0;
+#pragma unroll
+    for (int k = 0; k < WS_SCHED_CLASSES; k++) {
+        uint32_t tot;
+        off[k] = cbase + block_excl_scan_1024(cnt[k], s_w, tot);
+        cbase += tot;
+    }
+    for (uint32_t g = ga; g < gb; g++) {
+        const uint32_t k = cls_of(group_cost(g));
+        const uint32_t ta = max(g * G, r0), tb = min((g + 1u) * G, r1);
+        uint32_t dst = 0;
+#pragma unroll
+        for (int q = 0; q < WS_SCHED_CLASSES; q++)
+            if (k == (uint32_t)q) {
+                dst = off[q];
+                off[q] += tb - ta;
+            }
+        for (uint32_t t = ta; t < tb; t++) sc.perm[r0 + dst + (t - ta)] = t;
+    }
+}
+
+void wsk_schedule(hipStream_t s, WsSched s4, uint32_t ntiles4, WsSched s5, WsSched s5_costs, uint32_t ntiles5, uint32_t nclasses,
+                  uint32_t group_particles)
+{
+    nclasses = std::min<uint32_t>(nclasses, WS_SCHED_CLASSES);  // (0: outliers first, equal static shares)
+    s5.cost = s5_costs.cost;  // (the kernel reads costs and writes split / perm)
+    hipLaunchKernelGGL(k_schedule, dim3(16), dim3(WS_SCHED_BLOCK), 0, s, s4, ntiles4, s5, ntiles5, nclasses, group_particles);
 }
 
 // ---------------------------------------------------------------------------------

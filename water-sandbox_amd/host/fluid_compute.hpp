@@ -86,6 +86,7 @@ class FluidWorker {
     static FluidWorker build(const FluidStaticProps &props, const Gravity &gravity, const FluidContainer &container,
                              const std::vector<Vec3> &points, int device = 0)
     {
+        check_abi();
         FluidWorker w;
         w.n_ = (uint32_t)points.size();
         const ws_params p = make_params(props, gravity, container);
@@ -96,6 +97,13 @@ class FluidWorker {
         return w;
     }
 
+    // (a library of another ABI version lays ws_transport / ws_device_cfg out differently: refuse it before any struct crosses)
+    static void check_abi()
+    {
+        if (ws_abi_version() != WS_ABI_VERSION)
+            throw WsError(WS_ERR_UNSUPPORTED, "libwsfluid.so speaks another ABI version than include/wsfluid.h of this build");
+    }
+
     // The same worker as ONE x-slab of the domain (multi-GPU: one per GPU; the reference is single-GPU).
     // Every rank is handed ALL points -- FluidParticlesInitial, :82-85 -- and keeps what ws_slab_assign gives it.
     // n_ stays the GLOBAL particle count: read_positions / read_vec / reset / write_slice work on global, id-ordered
@@ -104,6 +112,7 @@ class FluidWorker {
                                   const std::vector<Vec3> &points, unsigned rank, unsigned world, const ws_transport &transport,
                                   int device = 0, unsigned flags = 0)
     {
+        check_abi();
         FluidWorker w;
         w.n_ = (uint32_t)points.size();
         const ws_params p = make_params(props, gravity, container);
