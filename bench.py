@@ -574,13 +574,14 @@ def main():
         npos, nparams = ws.workloads.make_workload("c4", "cloud")
         w4 = ws.FluidWorker(npos, nparams, device=local_rank, profile=True)
         w4.profile_select(neighbour_mask)
-        w4.run(10)
+        w4.run(5)
         w4.sync()
         t0 = time.perf_counter()
         w4.run(20)
         w4.sync()
         early = (time.perf_counter() - t0) / 20
-        w4.run(SETTLED_FROM - 30)
+        ns_early_traffic = step_traffic(load_window_counters("c4", "cloud", 5, 20), early * 1e3)
+        w4.run(SETTLED_FROM - 25)
         w4.sync()
         w4.profile_reset()
         t0 = time.perf_counter()
@@ -597,7 +598,12 @@ def main():
                       "particles": int(npos.shape[0]),
                       "steps_per_s": 1.0 / late, "ms_per_step": late * 1e3,
                       "window": "steps %d..%d (settled: the slowest state of the trajectory), one repetition" % (SETTLED_FROM, SETTLED_FROM + SETTLED_STEPS),
-                      "early": {"window": "steps 10..30", "steps_per_s": 1.0 / early, "ms_per_step": early * 1e3},
+                      "early": {"window": "steps 5..25", "steps_per_s": 1.0 / early, "ms_per_step": early * 1e3,
+                                "step_traffic": ns_early_traffic,
+                                "traffic_frac_of_measured_copy_bw": ns_early_traffic["frac_of_measured_copy_bw"] if ns_early_traffic else None,
+                                "meets_10M_at_60_at_40_percent_of_measured_hbm_bandwidth": bool(
+                                    ns_early_traffic and npos.shape[0] >= 10_000_000 and 1.0 / early >= 60.0
+                                    and ns_early_traffic["frac_of_measured_copy_bw"] >= 0.4)},
                       "meets_10M_at_60": bool(npos.shape[0] >= 10_000_000 and 1.0 / late >= 60.0),
                       "algorithmic_GBps_step": B_ALG_STEP * npos.shape[0] / late / 1e9,
                       "frac_of_measured_copy_bw_algorithmic": B_ALG_STEP * npos.shape[0] / late / 1e9 / HBM_COPY_GBS,

@@ -26,8 +26,8 @@ w.close()
 ref = None
 # settings: "0" = static shares; "c<classes>g<particles per group>" = the schedule with these parameters
 for setting in (sys.argv[4:] or ["0", "c4g1024"]):
-    os.environ["WS_TILE_SCHEDULE"] = {"0": "0", "outliers": "2"}.get(setting, "1")
-    if setting not in ("0", "outliers"):
+    os.environ["WS_TILE_SCHEDULE"] = "0" if setting == "0" else "1"
+    if setting != "0":
         os.environ["WS_SCHED_CLASSES"], os.environ["WS_SCHED_GROUP"] = setting[1:].split("g")
     best = None
     v = ws.FluidWorker(pos, params, library=L)

@@ -22,8 +22,8 @@ pos, params = ws.workloads.make_workload(cfg, "cloud")
 n = pos.shape[0]
 # SCHED=0 | c<classes>g<particles per group> in the environment: the tile schedule of the kernels
 setting = os.environ.get("SCHED", "0")
-os.environ["WS_TILE_SCHEDULE"] = {"0": "0", "outliers": "2"}.get(setting, "1")
-if setting not in ("0", "outliers"):
+os.environ["WS_TILE_SCHEDULE"] = "0" if setting == "0" else "1"
+if setting != "0":
     os.environ["WS_SCHED_CLASSES"], os.environ["WS_SCHED_GROUP"] = setting[1:].split("g")
 w = ws.FluidWorker(pos, params, library=L)
 w.run(warm)

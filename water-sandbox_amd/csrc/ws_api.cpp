@@ -423,7 +423,6 @@ void bound_pending(ws_handle *h)
 //     reordering of the tiles costs more in L2 locality than the shorter drain returns (K5 +4 ... +13 %).
 #define WS_SCHED_MIN_PARTICLES (1u << 17)
 #define WS_SCHED_MAX_PARTICLES (1u << 20)
-#define WS_SCHED_OUTLIERS_FROM (1u << 23)  // EXPERIMENT
 
 void free_schedule(ws_handle *h)
 {
@@ -448,22 +447,13 @@ ws_status alloc_schedule(ws_handle *h)
 {
     if (h->variant != WS_VARIANT_LISTED || h->slab) return WS_OK;
     uint32_t min_n = WS_SCHED_MIN_PARTICLES, max_n = WS_SCHED_MAX_PARTICLES;
-    uint32_t outliers_from = WS_SCHED_OUTLIERS_FROM;
-    if (const char *v = WS_DEV_ENV("WS_TILE_SCHEDULE")) {  // developer builds: 0 = never, 1 = the classes at every size, 2 = the outlier mode at every size (A/B runs)
+    if (const char *v = WS_DEV_ENV("WS_TILE_SCHEDULE")) {  // developer builds: 0 = never, 1 = at every size (A/B runs)
         min_n = 0;
-        max_n = atoi(v) == 1 ? 0xFFFFFFFFu : 0u;
-        outliers_from = atoi(v) == 2 ? 0u : 0xFFFFFFFFu;
+        max_n = atoi(v) ? 0xFFFFFFFFu : 0u;
     }
-    const bool classes = h->n <= max_n && h->n >= min_n, outliers = !classes && h->n >= outliers_from;
-    if (!classes && !outliers) return WS_OK;
-    if (outliers) {
-        h->sched_classes = 0;  // k_schedule: equal static shares, tiles that cost > 4 x the average first
-        h->sched_group = 1;
-    }
-    if (classes) {
-        if (const char *v = WS_DEV_ENV("WS_SCHED_CLASSES")) h->sched_classes = (uint32_t)atoi(v);
-        if (const char *v = WS_DEV_ENV("WS_SCHED_GROUP")) h->sched_group = (uint32_t)atoi(v);
-    }
+    if (h->n > max_n || h->n < min_n) return WS_OK;
+    if (const char *v = WS_DEV_ENV("WS_SCHED_CLASSES")) h->sched_classes = (uint32_t)atoi(v);
+    if (const char *v = WS_DEV_ENV("WS_SCHED_GROUP")) h->sched_group = (uint32_t)atoi(v);
     h->sched_tiles4 = (h->n + wsk_density_tile() - 1u) / wsk_density_tile();
     h->sched_tiles5 = (h->n + wsk_force_tile() - 1u) / wsk_force_tile();
     uint32_t *cost4 = nullptr;
@@ -505,11 +495,11 @@ void enqueue_step(ws_handle *h)
     }
     {
         Prof p(h, WS_K_SCATTER);
-        wsk_place(s, d, h->cid_cur, h->cur.rank, h->cur.pos, h->start, h->slot_tmp, h->id_tmp);
+        wsk_place(s, d, h->cid_cur, h->cur.rank, h->start, h->slot_tmp);
     }
     {
         Prof p(h, WS_K_REORDER);
-        wsk_reorder(s, d, h->slot_tmp, h->id_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
+        wsk_reorder(s, d, h->slot_tmp, h->cid_cur, h->start, h->cur, h->srt, h->cid_srt, h->sxyz, h->pred_stale);
     }
     if (sched) hipStreamWaitEvent(s, h->ev_sched_out, 0);  // (the previous step's k_schedule: long done; nothing before the first)
     {
@@ -627,11 +617,11 @@ void free_particle_arrays(ws_handle *h)
     hipFree(h->srt.pos); hipFree(h->srt.pv);
     hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
-    hipFree(h->slot_tmp); hipFree(h->id_tmp); hipFree(h->mask.words);
+    hipFree(h->slot_tmp); hipFree(h->mask.words);
     h->cur = WsSoA{};
     h->srt = WsSorted{};
     h->sxyz = WsXYZ{};
-    h->cid_cur = h->cid_srt = h->slot_tmp = h->id_tmp = nullptr;
+    h->cid_cur = h->cid_srt = h->slot_tmp = nullptr;
     h->accel = nullptr;
     h->mask = WsMask{nullptr, 0};
 }
@@ -850,7 +840,6 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
     CREATE_HIP(hipMalloc(&h->cid_srt, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->accel, n16));
     CREATE_HIP(hipMalloc(&h->slot_tmp, (size_t)n * 4));
-    CREATE_HIP(hipMalloc(&h->id_tmp, (size_t)n * 4 + 16));  // k_reorder reads 16 bytes at a time
     if (h->variant == WS_VARIANT_LISTED) {
         h->mask.stride = n;
         CREATE_HIP(hipMalloc(&h->mask.words, (size_t)wsk_mask_words() * n * 4));
@@ -1279,7 +1268,7 @@ ws_status ws_read_sort_view(ws_handle *h, uint32_t *keys_by_id, uint32_t *perm, 
         wsk_view_keys(s, h->dev, h->srt, h->v_keys, h->v_count);
     }
     wsk_scan(s, h->v_count, h->v_start, h->v_cursor, h->v_bsum, n, false, 0);
-    wsk_scatter(s, keys, nullptr, h->v_cursor, h->v_tmp, nullptr, n, nullptr);
+    wsk_scatter(s, keys, h->v_cursor, h->v_tmp, n, nullptr);
     wsk_view_fix(s, h->v_tmp, keys, h->v_start, h->v_perm, n);
     wsk_view_offsets(s, h->v_start, h->v_off, n);
     HIP_TRY(h, hipGetLastError());

@@ -193,7 +193,6 @@ struct ws_handle {
     int variant = WS_VARIANT_LISTED;  // density / near density ride in srt.pred(i).w / srt.vel(i).w
     float4 *accel = nullptr;      // acceleration in `srt` order
     uint32_t *slot_tmp = nullptr; // particle index per tentative slot
-    uint32_t *id_tmp = nullptr;   // particle id per tentative slot (canonical in-cell order)
     uint32_t *count = nullptr;    // per-cell particle count (histogram)
     uint32_t *cursor = nullptr;   // per-cell fill cursor
     uint32_t *start = nullptr;    // guard + ncells + 1 + guard exclusive starts
@@ -353,16 +352,13 @@ extern "C" void ws_rccl_transport_bind_stream(const ws_transport *t, void *strea
 void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32_t n);
 void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);
 void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count, uint32_t *rank);
-void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const float4 *pos_with_id,
-               const uint32_t *start, uint32_t *slot_tmp, uint32_t *id_tmp);
+void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const uint32_t *start, uint32_t *slot_tmp);
 void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t nitems,
               bool zero_count, uint32_t base);
 uint32_t wsk_scan_state_words(uint32_t nitems);
-void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
-                 uint32_t *id_tmp, uint32_t n, const uint32_t *n_dev);
-void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz,
-                 bool recompute_pred);
+void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n, const uint32_t *n_dev);
+void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur, const uint32_t *start, WsSoA cur,
+                 WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz, bool recompute_pred);
 void wsk_refresh_pred(hipStream_t s, const WsDev &d, WsSoA cur);
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz,

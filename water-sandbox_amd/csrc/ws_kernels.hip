@@ -420,92 +420,101 @@ void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cu
 }
 
 // ---------------------------------------------------------------------------------
-// K2': counting sort by cell.  Slot assignment inside a cell uses a returning atomic (arrival
-// order); k_reorder then ranks the members of each cell by PARTICLE ID, so the order inside a
-// cell is canonical: it depends on neither the previous order nor, across GPUs, on the order in
-// which migrated particles arrived.  Summation order -- hence every float -- is therefore a
-// function of the particle set alone, and an N-GPU run reproduces the 1-GPU run bit for bit.
+// K2': counting sort by cell.  k_place puts every particle's INDEX into a tentative slot of its cell (cell start + the
+// rank it drew when it was binned: arrival order); k_reorder then fetches the records through the indices and ranks the
+// members of each cell by PARTICLE ID, so the order inside a cell is canonical: it depends on neither the previous
+// order nor, across GPUs, on the order in which migrated particles arrived.  Summation order -- hence every float -- is
+// therefore a function of the particle set alone, and an N-GPU run reproduces the 1-GPU run bit for bit.
 // Slots are absolute indices into the sorted arrays (cell starts already include d.base).
+// Round 5: the ids the ranking compares come out of the records k_reorder fetches anyway (a workgroup shares them through
+// LDS: cell-mates are neighbours in the tentative order), so k_place no longer reads the 16-byte position records for
+// their id lane, nor scatters a second word per particle (12 B read + 4 B scattered write per particle instead of 24 + 8).
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict__ keys,
-                                                      const float4 *__restrict__ pos_with_id,
-                                                      uint32_t *__restrict__ cursor, uint32_t *__restrict__ slot_tmp,
-                                                      uint32_t *__restrict__ id_tmp, uint32_t n,
+// Placement through per-cell fill cursors (a slab's first step after an upload, where k_migrate_mark took the leavers
+// out of the histogram and the ranks drawn at binning have holes; and the reference-layout sort view, by bucket):
+// arrival order inside the cell, one returning atomic per run of lanes.
+__global__ void __launch_bounds__(WS_BLOCK) k_scatter(const uint32_t *__restrict__ keys, uint32_t *__restrict__ cursor,
+                                                      uint32_t *__restrict__ slot_tmp, uint32_t n,
                                                       const uint32_t *__restrict__ n_dev)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     bool active = i < (n_dev ? *n_dev : n);  // slab handles: n is an upper bound, the count lives on the device
     if (active && keys[i] == WS_DEAD) active = false;  // only after a migration overrun (the step is already flagged invalid)
     const uint32_t slot = wave_run_atomic_inc(cursor, active ? keys[i] : 0u, active);
-    if (!active) return;
-    slot_tmp[slot] = i;
-    if (id_tmp) id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
+    if (active) slot_tmp[slot] = i;
 }
 
 // The same placement from ranks taken when the particles were binned (the force kernel's epilogue, k_bin, or
 // k_migrate_fill for a slab's arrivals): slot = cell start + rank, no atomics.  The ranks of a cell are gap-free
 // on a slab as well: a particle that leaves is never binned (force epilogue), one that arrives draws the next rank.
-// cid / rank / pos_with_id are indexed from the first owned particle; slots are absolute.
+// cid / rank are indexed from the first owned particle; slots are absolute.
 __global__ void __launch_bounds__(WS_BLOCK) k_place(WsDev d, const uint32_t *__restrict__ cid,
                                                     const uint32_t *__restrict__ rank,
-                                                    const float4 *__restrict__ pos_with_id,
-                                                    const uint32_t *__restrict__ start, uint32_t *__restrict__ slot_tmp,
-                                                    uint32_t *__restrict__ id_tmp)
+                                                    const uint32_t *__restrict__ start, uint32_t *__restrict__ slot_tmp)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= ws_n(d)) return;
-    if (cid[i] == WS_DEAD) return;  // only after a migration overrun (the step is already flagged invalid)
-    const uint32_t slot = start[d.guard + cid[i]] + rank[i];
-    slot_tmp[slot] = i;
-    id_tmp[slot] = __float_as_uint(pos_with_id[i].w);
+    const uint32_t c = cid[i];
+    if (c == WS_DEAD) return;  // only after a migration overrun (the step is already flagged invalid)
+    slot_tmp[start[d.guard + c] + rank[i]] = i;
 }
 
-void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const float4 *pos_with_id,
-               const uint32_t *start, uint32_t *slot_tmp, uint32_t *id_tmp)
+void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const uint32_t *start, uint32_t *slot_tmp)
 {
-    hipLaunchKernelGGL(k_place, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cid, rank, pos_with_id, start, slot_tmp,
-                       id_tmp);
+    hipLaunchKernelGGL(k_place, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cid, rank, start, slot_tmp);
 }
 
-void wsk_scatter(hipStream_t s, const uint32_t *keys, const float4 *pos_with_id, uint32_t *cursor, uint32_t *slot_tmp,
-                 uint32_t *id_tmp, uint32_t n, const uint32_t *n_dev)
+void wsk_scatter(hipStream_t s, const uint32_t *keys, uint32_t *cursor, uint32_t *slot_tmp, uint32_t n, const uint32_t *n_dev)
 {
-    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, keys, pos_with_id, cursor, slot_tmp,
-                       id_tmp, n, n_dev);
+    hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, keys, cursor, slot_tmp, n, n_dev);
 }
 
 // `cur` and cid_cur are indexed from the first owned particle (the caller passes offset pointers);
-// srt / cid_srt / slot_tmp / id_tmp are indexed absolutely.
+// srt / cid_srt / slot_tmp are indexed absolutely.
 // RECOMPUTE_PRED: the force kernel's epilogue does not store the predicted positions it bins by -- they are
 // pos + vel * look-ahead of the values it does store, and the same two operations here give the same bits
 // (simulation.wgsl:307).  After an upload (ws_create, ws_reset, ws_write_particles, a slab's first step) the stored
 // `cur.pred` is used instead: the caller's predicted positions are taken as they are.
 #define WS_LOOKAHEAD 0.02f  // 1. / 50., simulation.wgsl:3
 typedef uint32_t nd_u4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive words, 4-byte aligned
+#ifndef WS_REORDER_BLOCK
+#define WS_REORDER_BLOCK 512  // 256 / 512 / 1024: C3 sparse step 0.4615 / 0.4602 / 0.4611 ms, C4 settled 9.411 / 9.387 / 9.371 (a cell that straddles the edge costs two dependent gathers per mate)
+#endif
 template <bool RECOMPUTE_PRED>
-__global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *__restrict__ slot_tmp,
-                                                      const uint32_t *__restrict__ id_tmp,
+__global__ void __launch_bounds__(WS_REORDER_BLOCK) k_reorder(WsDev d, const uint32_t *__restrict__ slot_tmp,
                                                       const uint32_t *__restrict__ cid_cur,
                                                       const uint32_t *__restrict__ start, WsSoA cur, WsSorted srt,
                                                       uint32_t *__restrict__ cid_srt, WsXYZ sxyz)
 {
-    const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (k >= ws_n(d)) return;
-    const uint32_t s = d.base + k;
-    const uint32_t i = slot_tmp[s];
-    const uint32_t id = id_tmp[s];
-    const uint32_t c = cid_cur[i];
-    if (c == WS_DEAD) return;  // a stale slot after a migration overrun (the step is already flagged invalid)
+    __shared__ uint32_t s_id[WS_REORDER_BLOCK];  // the ids of this workgroup's slots (0xFFFFFFFF: nothing there)
+    const uint32_t k = blockIdx.x * WS_REORDER_BLOCK + threadIdx.x;
+    const uint32_t s = d.base + k, s0 = d.base + blockIdx.x * WS_REORDER_BLOCK;
+    bool active = k < ws_n(d);
+    uint32_t i = 0, c = WS_DEAD;
+    if (active) {
+        i = slot_tmp[s];
+        c = cid_cur[i];
+        active = c != WS_DEAD;  // a stale slot after a migration overrun (the step is already flagged invalid)
+    }
+    float4 p = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu)), v = p;
+    if (active) {
+        p = cur.pos[i];
+        v = cur.vel[i];
+    }
+    const uint32_t id = __float_as_uint(p.w);
+    s_id[threadIdx.x] = id;
+    __syncthreads();
+    if (!active) return;
     const uint32_t b = start[d.guard + c], e = start[d.guard + c + 1];
     uint32_t rank = 0;
-    for (uint32_t t = b; t < e; t += 4) {  // four cell-mates per trip from ONE 16-B load (id_tmp is padded by four words)
-        const nd_u4u a = *reinterpret_cast<const nd_u4u *>(id_tmp + t);
-        const uint32_t left = e - t;
-        rank += (a[0] < id ? 1u : 0u) + ((left > 1u && a[1] < id) ? 1u : 0u) + ((left > 2u && a[2] < id) ? 1u : 0u) +
-                ((left > 3u && a[3] < id) ? 1u : 0u);
+    for (uint32_t t = b; t < e; t++) {
+        // cell-mates are neighbours in the tentative order: all but those of a cell that straddles the workgroup's edge
+        // sit in LDS; for the others the id comes the way this thread's own did
+        const uint32_t o = t - s0;
+        const uint32_t other = o < (uint32_t)WS_REORDER_BLOCK ? s_id[o] : __float_as_uint(cur.pos[slot_tmp[t]].w);
+        rank += other < id ? 1u : 0u;
     }
     const uint32_t dst = b + rank;
-    const float4 p = cur.pos[i], v = cur.vel[i];
     float4 q;
     if constexpr (RECOMPUTE_PRED)
         q = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
@@ -522,16 +531,15 @@ __global__ void __launch_bounds__(WS_BLOCK) k_reorder(WsDev d, const uint32_t *_
     cid_srt[dst] = c;
 }
 
-void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *id_tmp,
-                 const uint32_t *cid_cur, const uint32_t *start, WsSoA cur, WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz,
-                 bool recompute_pred)
+void wsk_reorder(hipStream_t s, const WsDev &d, const uint32_t *slot_tmp, const uint32_t *cid_cur, const uint32_t *start, WsSoA cur,
+                 WsSorted srt, uint32_t *cid_srt, WsXYZ sxyz, bool recompute_pred)
 {
     if (recompute_pred)
-        hipLaunchKernelGGL(k_reorder<true>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur,
-                           start, cur, srt, cid_srt, sxyz);
+        hipLaunchKernelGGL(k_reorder<true>, dim3(cdiv(d.n, WS_REORDER_BLOCK)), dim3(WS_REORDER_BLOCK), 0, s, d, slot_tmp, cid_cur, start, cur, srt,
+                           cid_srt, sxyz);
     else
-        hipLaunchKernelGGL(k_reorder<false>, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, slot_tmp, id_tmp, cid_cur,
-                           start, cur, srt, cid_srt, sxyz);
+        hipLaunchKernelGGL(k_reorder<false>, dim3(cdiv(d.n, WS_REORDER_BLOCK)), dim3(WS_REORDER_BLOCK), 0, s, d, slot_tmp, cid_cur, start, cur, srt,
+                           cid_srt, sxyz);
 }
 
 // cur.pred of the owned particles from their stored position and velocity (see k_reorder): for the paths off the
@@ -1450,8 +1458,7 @@ __global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_
     const uint32_t before_s = block_excl_scan_1024(mine_s, s_w, total_s);
     if (tid < 9u) s_cut[tid] = tid == 8u ? T : 0u;
     __syncthreads();
-    const bool outliers_only = nclasses == 0u;  // large handles: equal static shares, only the outliers go first (below)
-    if (total_s >= 8u && !outliers_only) {
+    if (total_s >= 8u) {
         // the thread whose tiles contain the k-th eighth of the total looks for the exact tile
         for (uint32_t k = 1; k < 8u; k++) {
             const unsigned long long target = (unsigned long long)total_s * k / 8u;
@@ -1516,12 +1523,7 @@ __global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_
     if ((tid & 63u) == 0u) atomicMax(&s_max, mx);
     __syncthreads();
     const uint32_t cmax = s_max + 1u;
-    // Outlier mode (handles above WS_SCHED_MAX_PARTICLES): class 0 = the tiles that cost more than four times the
-    // average -- a workgroup with a mask-overflow particle lives 0.8 ... 2.6 ms in the settled tall containers, where the
-    // average lives 0.12 ms, and a launch that starts such a tile late drains through it alone -- and class 1 = everybody
-    // else, in the sorted order's own sequence: the L2 locality of the static shares is untouched.
     auto cls_of = [&](uint32_t v) {  // 0 = the heaviest part of the cost range
-        if (outliers_only) return v > 4u * fill ? 0u : 1u;
         return (uint32_t)(((unsigned long long)(cmax - 1u - min(v, cmax - 1u)) * nclasses) / cmax);
     };
     uint32_t cnt[WS_SCHED_CLASSES];
@@ -1557,7 +1559,7 @@ __global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_
 void wsk_schedule(hipStream_t s, WsSched s4, uint32_t ntiles4, WsSched s5, WsSched s5_costs, uint32_t ntiles5, uint32_t nclasses,
                   uint32_t group_particles)
 {
-    nclasses = std::min<uint32_t>(nclasses, WS_SCHED_CLASSES);  // (0: outliers first, equal static shares)
+    nclasses = std::min<uint32_t>(std::max<uint32_t>(nclasses, 1u), WS_SCHED_CLASSES);
     s5.cost = s5_costs.cost;  // (the kernel reads costs and writes split / perm)
     hipLaunchKernelGGL(k_schedule, dim3(16), dim3(WS_SCHED_BLOCK), 0, s, s4, ntiles4, s5, ntiles5, nclasses, group_particles);
 }
