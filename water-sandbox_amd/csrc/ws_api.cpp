@@ -578,7 +578,7 @@ ws_status bin_current(ws_handle *h)
     HIP_TRY(h, hipMemsetAsync(h->count, 0, (size_t)h->dev.ncells * 4, h->stream));
     {
         Prof pr(h, WS_K_BIN);
-        wsk_bin(h->stream, h->dev, h->cur.pred, h->cid_cur, h->count, h->cur.rank);
+        wsk_bin(h->stream, h->dev, h->cur, h->cid_cur, h->count);
     }
     HIP_TRY(h, hipGetLastError());
     return WS_OK;
@@ -613,7 +613,7 @@ void drop_graphs(ws_handle *h)
 void free_particle_arrays(ws_handle *h)
 {
     drop_graphs(h);
-    hipFree(h->cur.pos); hipFree(h->cur.vel); hipFree(h->cur.pred); hipFree(h->cur.rank);
+    hipFree(h->cur.pv); hipFree(h->cur.pred); hipFree(h->cur.rank);
     hipFree(h->srt.pos); hipFree(h->srt.pv);
     hipFree(h->sxyz.x); hipFree(h->sxyz.y); hipFree(h->sxyz.z);
     hipFree(h->cid_cur); hipFree(h->cid_srt); hipFree(h->accel);
@@ -828,8 +828,7 @@ ws_status ws_create(const ws_params *params, const float *pos_xyz, uint32_t n, c
 #endif
     // +16 entries: phase 1 trips read up to U-1 slots past a run's end (masked, but must be mapped)
     const size_t n16 = ((size_t)n + 16) * 16;
-    CREATE_HIP(hipMalloc(&h->cur.pos, n16));
-    CREATE_HIP(hipMalloc(&h->cur.vel, n16));
+    CREATE_HIP(hipMalloc(&h->cur.pv, 2 * n16));
     CREATE_HIP(hipMalloc(&h->cur.pred, n16));
     CREATE_HIP(hipMalloc(&h->cur.rank, (size_t)n * 4));
     CREATE_HIP(hipMalloc(&h->srt.pos, n16));
@@ -1027,7 +1026,7 @@ ws_status ws_read_positions(ws_handle *h, float *out_xyz)
     const size_t bytes = (size_t)h->n * 12;
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
-    wsk_gather_positions(h->stream, h->cur.pos, (float *)h->stage, h->n);
+    wsk_gather_positions(h->stream, h->cur, (float *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out_xyz, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1093,7 +1092,7 @@ ws_status ws_read_positions_begin(ws_handle *h, float *out_xyz)
             HIP_TRY(h, hipMalloc(&h->rb_stage, bytes));
             h->rb_bytes = bytes;
         }
-        wsk_gather_positions(h->stream, h->cur.pos, h->rb_stage, h->n);
+        wsk_gather_positions(h->stream, h->cur, h->rb_stage, h->n);
         HIP_TRY(h, hipGetLastError());
         src = h->rb_stage;
     }
@@ -1140,7 +1139,7 @@ ws_status ws_read_speeds(ws_handle *h, float *out_speed)
     const size_t bytes = (size_t)h->n * 4;
     ws_status st = ensure_stage(h, bytes);
     if (st) return st;
-    wsk_gather_speeds(h->stream, h->cur.pos, h->cur.vel, (float *)h->stage, h->n);
+    wsk_gather_speeds(h->stream, h->cur, (float *)h->stage, h->n);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out_speed, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

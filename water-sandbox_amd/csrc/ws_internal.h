@@ -109,14 +109,19 @@ struct WsMask {
     uint32_t stride;  // particles per row
 };
 
-// SoA particle set (one of two ping-pong copies).
+// The particle set in the order of the last step: ONE 32-byte record {position, id | velocity, cell id} per particle
+// (round 5; two arrays until then): k_reorder fetches a particle through its index with two 16-byte loads of ONE line
+// (position, velocity and cell id used to be three scattered reads, a 128-byte line each once the fluid has mixed), and it
+// is the shape a migrating particle travels in.  The force kernel's epilogue writes it with full-line stores (lane pairs
+// exchange halves first: store_records).
 struct WsSoA {
-    float4 *pos;   // xyz = position, w = particle id (bits)
-    float4 *vel;   // xyz = velocity (sorted copy: w = near density after K4)
-    float4 *pred;  // xyz = predicted_position (sorted copy: w = density after K4)
+    float4 *pv;    // [2 i] = {position.xyz, particle id (bits)}, [2 i + 1] = {velocity.xyz, cell id (bits; = cid_cur[i])}
+    float4 *pred;  // xyz = predicted_position: what an upload supplied; the step loop does not maintain it (k_reorder)
     // Optional (single-GPU handles): the particle's arrival rank inside its cell, as returned by the histogram's
     // atomic when the particle was binned.  With it the sort places particles without a second round of atomics.
     uint32_t *rank;
+    __host__ __device__ float4 &pos(uint32_t i) const { return pv[2 * (size_t)i]; }
+    __host__ __device__ float4 &vel(uint32_t i) const { return pv[2 * (size_t)i + 1]; }
 };
 
 // The test-only build (tests/libwsfluid_refcheck.so, -DWS_WITH_REFCHECK -Itests/refcheck) adds a validation mode
@@ -351,7 +356,7 @@ extern "C" void ws_rccl_transport_bind_stream(const ws_transport *t, void *strea
 // ---- kernel launchers (ws_kernels.hip) -------------------------------------------
 void wsk_upload_positions(hipStream_t s, const float *xyz_dev, WsSoA cur, uint32_t n);
 void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur, uint32_t n);
-void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count, uint32_t *rank);
+void wsk_bin(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid, uint32_t *count);  // (cur / cid from the first particle to bin)
 void wsk_place(hipStream_t s, const WsDev &d, const uint32_t *cid, const uint32_t *rank, const uint32_t *start, uint32_t *slot_tmp);
 void wsk_scan(hipStream_t s, uint32_t *count, uint32_t *start_body, uint32_t *cursor, uint32_t *state, uint32_t nitems,
               bool zero_count, uint32_t base);
@@ -373,8 +378,8 @@ uint32_t wsk_mask_words(void);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
                WsMask mask, bool accel_only, const WsEventPair *ev = nullptr, WsSched sched = WsSched{});
-void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n);
-void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n);
+void wsk_gather_positions(hipStream_t s, WsSoA cur, float *out_xyz, uint32_t n);
+void wsk_gather_speeds(hipStream_t s, WsSoA cur, float *out, uint32_t n);
 void wsk_gather_particles(hipStream_t s, const WsDev &d, WsSoA cur, WsSorted srt, const float4 *accel, bool have_step,
                           ws_particle80 *out, uint32_t n);
 // reference-layout view

@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_upload_positions(const float *__re
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-    cur.pos[i] = make_float4(x, y, z, __uint_as_float(i));
-    cur.vel[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cur.pos(i) = make_float4(x, y, z, __uint_as_float(i));
+    cur.vel(i) = make_float4(0.f, 0.f, 0.f, 0.f);
     cur.pred[i] = make_float4(x, y, z, 0.f);
 }
 
@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_upload_particles(const ws_particle
     if (i >= n) return;
     const float4 *rec = reinterpret_cast<const float4 *>(in + i);
     const float4 p = rec[0], v = rec[2], q = rec[4];
-    cur.pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(i));
-    cur.vel[i] = make_float4(v.x, v.y, v.z, 0.f);
+    cur.pos(i) = make_float4(p.x, p.y, p.z, __uint_as_float(i));
+    cur.vel(i) = make_float4(v.x, v.y, v.z, 0.f);
     cur.pred[i] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
@@ -206,22 +206,23 @@ void wsk_upload_particles(hipStream_t s, const ws_particle80 *in_dev, WsSoA cur,
 // ---------------------------------------------------------------------------------
 #define WS_DEAD 0xFFFFFFFFu  // cell id of a slot whose particle has left the slab (slab handles)
 
-__global__ void __launch_bounds__(WS_BLOCK) k_bin(WsDev d, const float4 *__restrict__ pred,
-                                                  uint32_t *__restrict__ cid, uint32_t *__restrict__ count,
-                                                  uint32_t *__restrict__ rank)
+// (the cell id is kept twice: cid[i], which k_place streams, and the w lane of the particle's velocity record, which
+// k_reorder fetches with the record -- every writer of one writes the other)
+__global__ void __launch_bounds__(WS_BLOCK) k_bin(WsDev d, WsSoA cur, uint32_t *__restrict__ cid, uint32_t *__restrict__ count)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= ws_n(d)) return;
-    const float4 p = pred[i];
+    const float4 p = cur.pred[i];
     const uint32_t c = grid_cell(d, p.x, p.y, p.z);
     cid[i] = c;
+    cur.vel(i).w = __uint_as_float(c);
     const uint32_t r = atomicAdd(&count[c], 1u);
-    if (rank) rank[i] = r;
+    if (cur.rank) cur.rank[i] = r;
 }
 
-void wsk_bin(hipStream_t s, const WsDev &d, const float4 *pred, uint32_t *cid, uint32_t *count, uint32_t *rank)
+void wsk_bin(hipStream_t s, const WsDev &d, WsSoA cur, uint32_t *cid, uint32_t *count)
 {
-    hipLaunchKernelGGL(k_bin, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, pred, cid, count, rank);
+    hipLaunchKernelGGL(k_bin, dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, d, cur, cid, count);
 }
 
 // ---------------------------------------------------------------------------------
@@ -491,15 +492,15 @@ __global__ void __launch_bounds__(WS_REORDER_BLOCK) k_reorder(WsDev d, const uin
     const uint32_t s = d.base + k, s0 = d.base + blockIdx.x * WS_REORDER_BLOCK;
     bool active = k < ws_n(d);
     uint32_t i = 0, c = WS_DEAD;
-    if (active) {
-        i = slot_tmp[s];
-        c = cid_cur[i];
-        active = c != WS_DEAD;  // a stale slot after a migration overrun (the step is already flagged invalid)
-    }
     float4 p = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu)), v = p;
     if (active) {
-        p = cur.pos[i];
-        v = cur.vel[i];
+        i = slot_tmp[s];
+        p = cur.pos(i);  // the two halves of ONE 32-byte record: position with the id, velocity with the cell id
+        v = cur.vel(i);
+        c = __float_as_uint(v.w);
+        v.w = 0.f;
+        active = c != WS_DEAD;  // a stale slot after a migration overrun (the step is already flagged invalid)
+        if (!active) p.w = __uint_as_float(0xFFFFFFFFu);
     }
     const uint32_t id = __float_as_uint(p.w);
     s_id[threadIdx.x] = id;
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(WS_REORDER_BLOCK) k_reorder(WsDev d, const uin
         // cell-mates are neighbours in the tentative order: all but those of a cell that straddles the workgroup's edge
         // sit in LDS; for the others the id comes the way this thread's own did
         const uint32_t o = t - s0;
-        const uint32_t other = o < (uint32_t)WS_REORDER_BLOCK ? s_id[o] : __float_as_uint(cur.pos[slot_tmp[t]].w);
+        const uint32_t other = o < (uint32_t)WS_REORDER_BLOCK ? s_id[o] : __float_as_uint(cur.pos(slot_tmp[t]).w);
         rank += other < id ? 1u : 0u;
     }
     const uint32_t dst = b + rank;
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_refresh_pred(WsDev d, WsSoA cur)
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (k >= ws_n(d)) return;
     const uint32_t i = d.base + k;
-    const float4 p = cur.pos[i], v = cur.vel[i];
+    const float4 p = cur.pos(i), v = cur.vel(i);
     cur.pred[i] = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
 }
 
@@ -772,15 +773,48 @@ __device__ __forceinline__ void migrate_out(const WsDev &d, const WsMig &m, uint
     rec[1] = vel;
 }
 
+// The new record of a particle -- {position, id}, {velocity, cell id} -- as eight scalars, and whether there is one to
+// store (not in the ACCEL_ONLY pass, not for shadow lanes).
+struct WsNewRecord {
+    float px, py, pz, pw, vx, vy, vz, vw;
+    int have;
+};
+
+// Store the wave's new records with FULL-LINE stores.  A lane holds both halves of its particle's 32-byte record; stored
+// as they are, the two 16-byte stores of a wave would each touch every second half-line (measured: K5 +13 % in the sparse
+// state).  So lanes exchange halves first: for each half of the wave, lane l takes half (l & 1) of the record of lane
+// 32 h + (l >> 1) -- consecutive lanes then write consecutive 16 bytes (the wave's particles are consecutive slots except
+// across the jump of a slab's two-range span, which only splits one store in two).  Every lane of the wave must call.
+__device__ __forceinline__ void store_records(const WsDev &d, WsSoA out, uint32_t i, const WsNewRecord &r)
+{
+    const int lane = threadIdx.x & 63;
+    const bool odd = (lane & 1) != 0;
+    // the lanes that have a record are a prefix of the wave (lanes past the end of the range shadow its last particle)
+    const int nhave = __popcll(__ballot(r.have != 0));
+    // ... and their particles are consecutive slots, except across the jump of a slab's two-range span
+    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    auto from = [](int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); };
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int src = 32 * h + (lane >> 1), a = src << 2;
+        const uint32_t si = d.dyn ? (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)i) : i0 + (uint32_t)src;
+        const float px = from(a, r.px), py = from(a, r.py), pz = from(a, r.pz), pw = from(a, r.pw);
+        const float vx = from(a, r.vx), vy = from(a, r.vy), vz = from(a, r.vz), vw = from(a, r.vw);
+        const float4 w = make_float4(odd ? vx : px, odd ? vy : py, odd ? vz : pz, odd ? vw : pw);
+        if (src < nhave) out.pv[2 * (size_t)si + (odd ? 1u : 0u)] = w;
+    }
+}
+
 // K5 epilogue (simulation.wgsl:265-268) + K6 integrate (:279-309) + next step's K1 binning.
 // The acceleration itself (the reference's `acceleration` field, read by nothing but the 80-byte record view) is not
 // stored by the step: ACCEL_ONLY = the same kernel run again over the same sorted state, on demand, storing just
 // that (ws_read_particles; same code, same inputs, same visit order: the bits the step used).
+// Leaves the particle's new record in `rec` (the caller stores the wave's records together: store_records).
 template <bool ACCEL_ONLY>
-__device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const ForceAcc &a, float rho_x, float4 vel,
-                                                          uint32_t i, const float4 *__restrict__ pos, WsSoA out,
-                                                          float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
-                                                          uint32_t *__restrict__ count)
+__device__ __forceinline__ void force_integrate_bin(const WsDev &d, const ForceAcc &a, float rho_x, float4 vel, uint32_t i,
+                                                    const float4 *__restrict__ pos, WsSoA out, float4 *__restrict__ accel,
+                                                    uint32_t *__restrict__ cid_out, uint32_t *__restrict__ count,
+                                                    WsNewRecord &rec)
 {
     const float accx = a.pfx / rho_x + a.vfx * d.viscosity;
     const float accy = a.pfy / rho_x + a.vfy * d.viscosity;
@@ -802,9 +836,7 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
     if (py < d.ext_min[1]) { vy *= nd; py = d.ext_min[1]; } else if (py > d.ext_max[1]) { vy *= nd; py = d.ext_max[1]; }
     if (pz < d.ext_min[2]) { vz *= nd; pz = d.ext_min[2]; } else if (pz > d.ext_max[2]) { vz *= nd; pz = d.ext_max[2]; }
     const float qx = px + vx * WS_LOOKAHEAD, qy = py + vy * WS_LOOKAHEAD, qz = pz + vz * WS_LOOKAHEAD;
-    out.pos[i] = make_float4(px, py, pz, p0.w);
-    out.vel[i] = make_float4(vx, vy, vz, 0.f);
-    // (the predicted position is not stored: k_reorder recomputes it from the two records above, same bits)
+    // (the predicted position is not stored: k_reorder recomputes it from the record, same bits)
 
     // next step's hash_particles (simulation.wgsl:130-141) on the dense grid
     const uint32_t nc = grid_cell(d, qx, qy, qz);
@@ -815,7 +847,11 @@ __device__ __forceinline__ void force_store_integrate_bin(const WsDev &d, const 
         const uint32_t rowy = (uint32_t)(d.dim[1] * d.dim[2]);
         stays = nc >= rowy && nc < (uint32_t)(d.dim[0] - 1) * rowy;
     }
-    cid_out[i] = stays ? nc : WS_DEAD;
+    const uint32_t cell = stays ? nc : WS_DEAD;
+    cid_out[i] = cell;
+    rec.px = px; rec.py = py; rec.pz = pz; rec.pw = p0.w;
+    rec.vx = vx; rec.vy = vy; rec.vz = vz; rec.vw = __uint_as_float(cell);
+    rec.have = 1;
     const uint32_t r = wave_run_atomic_inc(count, nc, stays);  // one atomic per run of lanes that moved into the same cell
     if (out.rank) out.rank[i] = r;  // arrival rank inside the cell: the sort's tentative slot, without more atomics
     if (!stays) migrate_out(d, *d.mig, i, make_float4(px, py, pz, p0.w), make_float4(vx, vy, vz, 0.f), make_float4(qx, qy, qz, 0.f));
@@ -904,15 +940,20 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 {
     const WsSpan sp = ws_span(d, start);
     const uint32_t v = blockIdx.x * WS_BLOCK + threadIdx.x;
-    if (v >= sp.len) return;
-    const uint32_t i = span_at(sp, v);
+    if (sp.len == 0u || (blockIdx.x * WS_BLOCK + (threadIdx.x & ~63u)) >= sp.len) return;  // (whole waves only: a wave stores its records together)
+    const bool valid = v < sp.len;
+    const uint32_t i = span_at(sp, valid ? v : sp.len - 1u);  // lanes past the end shadow the last particle
     const float4 o = srt.pred(i);    // w = own density
     const float4 vel = srt.vel(i);   // w = own near density
-    const float pressure = d.pressure_scalar * (o.w - d.target_density);
-    const float near_pressure = d.near_pressure_scalar * vel.w;
-    ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    force_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, i, o, vel, (int)cid_srt[i], pressure, near_pressure, acc);
-    force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
+    WsNewRecord rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+    if (valid) {
+        const float pressure = d.pressure_scalar * (o.w - d.target_density);
+        const float near_pressure = d.near_pressure_scalar * vel.w;
+        ForceAcc acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        force_sweep_simple<ALIAS, IEEE>(d, start, srt, mult, i, o, vel, (int)cid_srt[i], pressure, near_pressure, acc);
+        force_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count, rec);
+    }
+    if constexpr (!ACCEL_ONLY) store_records(d, out, i, rec);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1275,7 +1316,9 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
     } else if (valid) {
         force_sweep_simple<false, IEEE, CUT ? 1 : 0>(d, start, srt, nullptr, i, o, vel, c, pressure, near_pressure, acc);
     }
-    if (valid) force_store_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count);
+    WsNewRecord rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+    if (valid) force_integrate_bin<ACCEL_ONLY>(d, acc, o.w, vel, i, srt.pos, out, accel, cid_out, count, rec);
+    if constexpr (!ACCEL_ONLY) store_records(d, out, i, rec);  // (every lane of the wave: the halves change lanes first)
 }
 
 // (SCHED: see k_density_listed)
@@ -1373,7 +1416,7 @@ void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uin
     else launch_density<false>(s, d, start, cid_srt, srt, mult, alias, variant, stats, mask, sxyz, ev, sched);
 }
 
-// accel_only: nothing but accel[i] is written (see force_store_integrate_bin) -- the on-demand pass of the record views
+// accel_only: nothing but accel[i] is written (see force_integrate_bin) -- the on-demand pass of the record views
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,
                WsMask mask, bool accel_only, const WsEventPair *ev, WsSched sched)
@@ -1567,38 +1610,35 @@ void wsk_schedule(hipStream_t s, WsSched s4, uint32_t ntiles4, WsSched s5, WsSch
 // ---------------------------------------------------------------------------------
 // readback in original-id order (update(), src/fluid_compute.rs:478-485)
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WS_BLOCK) k_gather_positions(const float4 *__restrict__ pos, float *__restrict__ out,
-                                                               uint32_t n)
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_positions(WsSoA cur, float *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const float4 p = pos[i];
+    const float4 p = cur.pos(i);
     const size_t id = __float_as_uint(p.w);
     out[3 * id] = p.x;
     out[3 * id + 1] = p.y;
     out[3 * id + 2] = p.z;
 }
 
-void wsk_gather_positions(hipStream_t s, const float4 *pos, float *out_xyz, uint32_t n)
+void wsk_gather_positions(hipStream_t s, WsSoA cur, float *out_xyz, uint32_t n)
 {
-    hipLaunchKernelGGL(k_gather_positions, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, out_xyz, n);
+    hipLaunchKernelGGL(k_gather_positions, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, cur, out_xyz, n);
 }
 
 // `velocity.length()` per particle, the quantity of the reference's (commented-out) speed colouring,
 // src/fluid_compute.rs:489-502; same left-to-right sum as the WGSL length() restatement
-__global__ void __launch_bounds__(WS_BLOCK) k_gather_speeds(const float4 *__restrict__ pos,
-                                                            const float4 *__restrict__ vel, float *__restrict__ out,
-                                                            uint32_t n)
+__global__ void __launch_bounds__(WS_BLOCK) k_gather_speeds(WsSoA cur, float *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const float4 v = vel[i];
-    out[__float_as_uint(pos[i].w)] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float4 v = cur.vel(i);
+    out[__float_as_uint(cur.pos(i).w)] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
 }
 
-void wsk_gather_speeds(hipStream_t s, const float4 *pos, const float4 *vel, float *out, uint32_t n)
+void wsk_gather_speeds(hipStream_t s, WsSoA cur, float *out, uint32_t n)
 {
-    hipLaunchKernelGGL(k_gather_speeds, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, pos, vel, out, n);
+    hipLaunchKernelGGL(k_gather_speeds, dim3(cdiv(n, WS_BLOCK)), dim3(WS_BLOCK), 0, s, cur, out, n);
 }
 
 __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cur, WsSorted srt,
@@ -1607,7 +1647,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_particles(WsDev d, WsSoA cu
 {
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
+    const float4 p = cur.pos(i), v = cur.vel(i), q = cur.pred[i];
     const size_t id = __float_as_uint(p.w);
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_step) {
@@ -1749,7 +1789,9 @@ __global__ void __launch_bounds__(WS_BLOCK) k_migrate_mark(WsDev d, WsSoA cur, u
     if (c >= rowy && c < (uint32_t)(d.dim[0] - 1) * rowy) return;
     atomicSub(&count[c], 1u);
     cid_cur[i] = WS_DEAD;
-    const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
+    const float4 p = cur.pos(i), vc = cur.vel(i), q = cur.pred[i];
+    const float4 v = make_float4(vc.x, vc.y, vc.z, 0.f);
+    cur.vel(i).w = __uint_as_float(WS_DEAD);
     // (loads hand every particle to the slab its PREDICTED position lies in, so nothing leaves here unless the host's own
     // assignment at ws_slab_create disagrees with the device's -- at rest.  A migration record does not carry the
     // predicted position: one that the receiver could not reproduce must not travel silently.)
@@ -1928,15 +1970,15 @@ __global__ void __launch_bounds__(WS_FILL_THREADS) k_migrate_fill(WsDev d, uint3
             const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 2 * (size_t)(tag == 3u ? idx % far_cap : idx);
             const float4 p = rec[0], v = rec[1];
             const float4 q = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
-            cur.pos[to] = p;
-            cur.vel[to] = v;
-            cur.pred[to] = q;
             const uint32_t c = grid_cell(d, q.x, q.y, q.z);
+            cur.pos(to) = p;
+            cur.vel(to) = make_float4(v.x, v.y, v.z, __uint_as_float(c));
+            cur.pred[to] = q;
             cid_cur[to] = c;
             cur.rank[to] = atomicAdd(&count[c], 1u);  // the next rank of its cell (k_place)
         } else {
-            cur.pos[to] = cur.pos[idx];
-            cur.vel[to] = cur.vel[idx];
+            cur.pos(to) = cur.pos(idx);
+            cur.vel(to) = cur.vel(idx);
             cur.pred[to] = cur.pred[idx];
             cid_cur[to] = cid_cur[idx];
             cur.rank[to] = cur.rank[idx];
@@ -2085,15 +2127,15 @@ __global__ void __launch_bounds__(WS_BLOCK) k_fill_apply(WsDev d, const uint32_t
         const float4 *rec = reinterpret_cast<const float4 *>(msg + WS_HDR_WORDS) + 2 * (size_t)(tag == 3u ? idx % far_cap : idx);
         const float4 p = rec[0], v = rec[1];
         const float4 q = make_float4(p.x + v.x * WS_LOOKAHEAD, p.y + v.y * WS_LOOKAHEAD, p.z + v.z * WS_LOOKAHEAD, 0.f);
-        cur.pos[to] = p;
-        cur.vel[to] = v;
-        cur.pred[to] = q;
         const uint32_t c = grid_cell(d, q.x, q.y, q.z);
+        cur.pos(to) = p;
+        cur.vel(to) = make_float4(v.x, v.y, v.z, __uint_as_float(c));
+        cur.pred[to] = q;
         cid_cur[to] = c;
         cur.rank[to] = atomicAdd(&count[c], 1u);  // the next rank of its cell (k_place)
     } else {
-        cur.pos[to] = cur.pos[idx];
-        cur.vel[to] = cur.vel[idx];
+        cur.pos(to) = cur.pos(idx);
+        cur.vel(to) = cur.vel(idx);
         cur.pred[to] = cur.pred[idx];
         cid_cur[to] = cid_cur[idx];
         cur.rank[to] = cur.rank[idx];
@@ -2275,7 +2317,7 @@ __global__ void __launch_bounds__(WS_BLOCK) k_gather_slab(WsDev d, WsSoA cur, Ws
     const uint32_t k = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (k >= ws_n(d)) return;
     const uint32_t i = d.base + k;
-    const float4 p = cur.pos[i], v = cur.vel[i], q = cur.pred[i];
+    const float4 p = cur.pos(i), v = cur.vel(i), q = cur.pred[i];
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (have_step) {
         dp.x = srt.pred(i).w;
@@ -2308,8 +2350,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_upload_positions_ids(const float *
     const uint32_t i = blockIdx.x * WS_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-    cur.pos[i] = make_float4(x, y, z, __uint_as_float(ids[i]));
-    cur.vel[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cur.pos(i) = make_float4(x, y, z, __uint_as_float(ids[i]));
+    cur.vel(i) = make_float4(0.f, 0.f, 0.f, 0.f);
     cur.pred[i] = make_float4(x, y, z, 0.f);
 }
 
@@ -2359,20 +2401,20 @@ __global__ void __launch_bounds__(WS_BLOCK) k_slab_pack(WsDev d, WsSoA cur, WsSo
         rec[1] = ref_hash_key(d, q.x, q.y, q.z);
         return;
     }
-    const float4 p = cur.pos[i];
+    const float4 p = cur.pos(i);
     rec[0] = __float_as_uint(p.w);
     if constexpr (KIND == WS_PACK_POS) {
         f[0] = p.x; f[1] = p.y; f[2] = p.z;
     } else if constexpr (KIND == WS_PACK_SPEED) {
-        const float4 v = cur.vel[i];
+        const float4 v = cur.vel(i);
         f[0] = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
     } else if constexpr (KIND == WS_PACK_STATE) {
-        const float4 v = cur.vel[i], q = cur.pred[i];
+        const float4 v = cur.vel(i), q = cur.pred[i];
         f[0] = p.x; f[1] = p.y; f[2] = p.z;
         f[3] = v.x; f[4] = v.y; f[5] = v.z;
         f[6] = q.x; f[7] = q.y; f[8] = q.z;
     } else {  // the 80-byte record (k_gather_slab's fields)
-        const float4 v = cur.vel[i], q = cur.pred[i];
+        const float4 v = cur.vel(i), q = cur.pred[i];
         float4 dp = make_float4(0.f, 0.f, 0.f, 0.f), a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (have_step) {
             dp.x = srt.pred(i).w;
@@ -2495,8 +2537,8 @@ __global__ void __launch_bounds__(WS_BLOCK) k_slab_select(WsDev d, const uint32_
         return;
     }
     const uint32_t i = d.base + slot;
-    cur.pos[i] = make_float4(p.x, p.y, p.z, __uint_as_float(id));
-    cur.vel[i] = make_float4(v.x, v.y, v.z, 0.f);
+    cur.pos(i) = make_float4(p.x, p.y, p.z, __uint_as_float(id));
+    cur.vel(i) = make_float4(v.x, v.y, v.z, 0.f);
     cur.pred[i] = make_float4(q.x, q.y, q.z, 0.f);
 }
 
