@@ -27,12 +27,14 @@ def per_kernel(kind, counter, scale):
 fetch, write = per_kernel("fetch", "FETCH_SIZE", 1024.0), per_kernel("write", "WRITE_SIZE", 1024.0)
 n32, n64, n128 = (per_kernel("rdsize", "TCC_EA0_RDREQ_%s_sum" % s, 1.0) for s in ("32B", "64B", "128B"))
 read = {k: 32.0 * n32.get(k, 0.0) + 64.0 * n64.get(k, 0.0) + 128.0 * n128.get(k, 0.0) for k in set(n32) | set(n64) | set(n128)}
-# calibration in this window: k_reorder<true> reads slot_tmp (4) + id_tmp (4) + cid (4) + two 16-B records and its
-# cell-mates' ids and cell starts (cached), and writes 3 x 16 + 4 + 3 x 4 B per particle
-cal_read_expected, cal_write_expected = n * (4 + 4 + 4 + 32), n * (48 + 4 + 12)
+# calibration in this window: k_reorder<true> reads, per particle, its slot's index (4 B) and ONE 32-byte record {position,
+# id | velocity, cell id} through it (round 5; rounds 1-4: index + id + cell id + two 16-byte records = 44 B, the figure
+# `read_expected_r04` keeps for comparison), plus two cell starts (cached), and writes 3 x 16 + 4 + 3 x 4 B
+cal_read_expected, cal_write_expected = n * (4 + 32), n * (48 + 4 + 12)
 ro = "k_reorder<true>"
 cal = {"kernel": ro, "read_expected_at_least": cal_read_expected, "read_resolved": read.get(ro),
-       "read_resolved_over_expected": read.get(ro, 0.0) / cal_read_expected, "fetch_size_raw": fetch.get(ro),
+       "read_resolved_over_expected": read.get(ro, 0.0) / cal_read_expected, "read_expected_r04": n * 44,
+       "read_resolved_over_expected_r04": read.get(ro, 0.0) / (n * 44.0), "fetch_size_raw": fetch.get(ro),
        "two_x_fetch_size_over_expected": 2.0 * fetch.get(ro, 0.0) / cal_read_expected,
        "requests": {"32B": n32.get(ro), "64B": n64.get(ro), "128B": n128.get(ro)},
        "write_expected": cal_write_expected, "write_raw": write.get(ro)}
