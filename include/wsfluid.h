@@ -321,7 +321,7 @@ void ws_rccl_transport_destroy(ws_transport *t);
 const char *ws_rccl_last_error(void);
 /* Communicators the transport drives: 2 = the step's two streams (migration / all-to-all on the handle's stream, halos on
  * its communication stream) each keep to a communicator of their own (the second one is split off the first), so no
- * communicator ever sees operations from two streams; 1 = WS_RCCL_SINGLE_COMM=1 or an RCCL without ncclCommSplit. */
+ * communicator ever sees operations from two streams; 1 = an RCCL without ncclCommSplit (or the developer build's WS_RCCL_SINGLE_COMM=1 hook). */
 uint32_t ws_rccl_transport_communicators(const ws_transport *t);
 
 /* A ws_transport for several slabs inside ONE process, one host thread per slab (one GPU or several): plain
@@ -419,8 +419,9 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * more than one slab towards ONE destination rank in one step and out[10] = the capacity of a far message (one per destination); out[11..13] = the records the migration, halo
  * and far messages carry: with exact sizes (the default) what the LAST step's carried, with WS_FLAG_LAGGED_MESSAGES what
  * the NEXT step's will (sized from what every rank reported a few steps ago; the capacities with
- * WS_SLAB_FIXED_MESSAGES=1); 0 without peers; out[14] = how often ws_step has waited for message sizes so far (two per
- * step with exact sizes, never with WS_FLAG_LAGGED_MESSAGES); the rest reserved. */
+ * WS_FLAG_FIXED_MESSAGES); 0 without peers; out[14] = how often ws_step has waited for message sizes so far (two per
+ * step with exact sizes, never with WS_FLAG_LAGGED_MESSAGES); out[15] = 1 when the cost-guided tile schedule drives the
+ * neighbour kernels (single-GPU handles of 2^17 .. 2^20 particles, not in a captured step: DESIGN.md 3). */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

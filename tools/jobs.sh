@@ -9,29 +9,7 @@ R=r05
 out=gpurun_out/$R; mkdir -p $out
 job=$1; shift
 
-counters() {  # counters <cfg> <particles> <warm> <steps> : kernel trace + traffic + SQ/TA passes of one window
-  local cfg=$1 n=$2 warm=$3 steps=$4
-  tools/traffic.sh $cfg cloud $warm $steps && python3 tools/traffic_report.py $cfg cloud $warm $steps $n $out/traffic_$cfg.json > /dev/null
-  echo "traffic $cfg w$warm done"
-  tools/pmc.sh ${R}${cfg}w$warm $cfg cloud $warm $steps abc > $out/pmc_${cfg}_w$warm.log 2>&1
-  python3 tools/pmc_windows.py ${R}${cfg}w$warm $cfg cloud $warm $steps $out/pmc_windows_$cfg.json > /dev/null
-  echo "pmc $cfg w$warm done"
-}
-
 case $job in
-c4_counters)  # the north-star size under the counters, both windows
-  rm -rf $out/rocprof_c4
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/rocprof_c4 -- python3 bench.py --config c4 --gpus 1 --steps 20 --warmup 5 --reps 1 --no-cpu-baseline --no-ieee --no-readback --no-north-star > $out/rocprof_c4.json 2> $out/rocprof_c4.err || exit 1
-  python3 tools/window_stats.py $(ls $out/rocprof_c4/*/*_kernel_trace.csv | head -1) 5 20 > $out/rocprof_c4_windows.json
-  cp $(ls $out/rocprof_c4/*/*_kernel_stats.csv | head -1) $out/rocprof_c4_kernel_stats.csv
-  echo "trace done"
-  counters c4 16777216 5 20
-  counters c4 16777216 400 100
-  ;;
-c3_counters)
-  counters c3 4194304 5 20
-  counters c3 4194304 400 100
-  ;;
 tests)
   timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > $out/pytest_gpu.log 2>&1; rc=$?
   echo "pytest exit $rc"; tail -5 $out/pytest_gpu.log; exit $rc
@@ -43,35 +21,11 @@ bench)
 ablate)  # ablate <warm> <lib> [<lib> ...] : one step of each tools/ab/lib<name>.so from the same state
   python3 tools/ablate.py "$@" 2>&1 | tee -a $out/ablate.log
   ;;
-chunk_ab)  # chunk_ab <cfg> <state step> <steps> <chunks...>
-  python3 tools/chunk_ab.py "$@" 2>&1 | tee -a $out/chunk_ab.log
-  ;;
-chunk_trace)  # chunk_trace <cfg> <state step> <chunks> : kernel timeline of a few chunked steps
-  rm -rf $out/chunk_trace
-  rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$out/chunk_trace -- python3 tools/chunk_ab.py $1 $2 6 $3 > $out/chunk_trace.log 2>&1
-  python3 tools/chunk_timeline.py $(ls $out/chunk_trace/*/*_kernel_trace.csv | head -1) | tee $out/chunk_timeline_$1_$2_c$3.txt
-  ;;
 wg_timeline)  # wg_timeline <cfg> <state step>
   python3 tools/wg_timeline.py "$@" 2>&1 | tee -a $out/wg_timeline.log
   ;;
 sched_ab)  # sched_ab <cfg> <state step> <steps>
   python3 tools/sched_ab.py "$@" 2>&1 | tee -a $out/sched_ab.log
-  ;;
-tcc)  # tcc <cfg> <warm> <steps> : L2 hit / miss counters of one window
-  tools/pmc.sh ${R}tcc$1w$2 $1 cloud $2 $3 t > $out/pmc_tcc_$1_w$2.log 2>&1
-  python3 - $1 $2 $3 <<'PY' | tee -a $out/tcc.log
-import collections, csv, glob, json, os, sys
-cfg, warm, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-f = max(glob.glob("gpurun_out/pmc_r05tcc%sw%d_t/*/*_counter_collection.csv" % (cfg, warm)), key=os.path.getmtime)
-vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(f)):
-    vals[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, cs in vals.items():
-    if k.startswith("k_") and all(len(v) >= steps for v in cs.values()):
-        m = {c: sum(v[-steps:]) / steps for c, v in cs.items()}
-        m["hit_rate"] = m.get("TCC_HIT_sum", 0) / max(m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0), 1)
-        print(json.dumps({"config": cfg, "warmup": warm, "kernel": k, **{c: round(v, 3) for c, v in m.items()}}))
-PY
   ;;
 slab_timeline)  # the two-slab C3x2 step under the kernel trace, communication stream at the highest / the default priority
   mkdir -p $out/slab
@@ -144,6 +98,9 @@ mask_words)  # the accept-mask size at C5 settled (tools/ab/l
   ;;
 lib_ab)  # lib_ab <cfg> <state step> <steps> <name...> : steady-state A/B of tools/ab/lib<name>.so
   python3 tools/lib_ab.py "$@" 2>&1 | tee -a $out/lib_ab.log
+  ;;
+long_identity)  # long_identity <cfg> <steps>
+  python3 tools/long_identity.py "$@" 2>&1 | tee -a $out/long_identity.log
   ;;
 *)
   echo "unknown job $job"; exit 2

@@ -1318,6 +1318,7 @@ ws_status ws_read_stats(ws_handle *h, uint32_t out[16])
     HIP_TRY(h, copy_now(h, out, h->stats, 64, hipMemcpyDeviceToHost));
     for (int c = 0; c < 3; c++) out[1 + c] = (uint32_t)h->dev.cm[c];  // reference cells merged per grid cell (host-side)
     out[4] = (uint32_t)(h->slab ? h->slab->graph_steps : h->graph_steps);  // steps replayed from a captured graph
+    out[15] = (h->sched_on && !h->alias && !(h->flags & WS_FLAG_GRAPH)) ? 1u : 0u;  // the cost-guided tile schedule drives K4 / K5
     if (h->slab) {  // how close the fixed message capacities came to overrunning, since the last load
         uint32_t dyn[WS_DYN_WORDS];
         HIP_TRY(h, copy_now(h, dyn, h->slab->dyn, sizeof dyn, hipMemcpyDeviceToHost));

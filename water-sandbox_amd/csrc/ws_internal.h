@@ -338,7 +338,7 @@ struct WsSlab {
     // halo / compute overlap: the halos travel on `comm` while the particles that need no ghosts compute
     hipStream_t comm = nullptr, copy = nullptr;
     hipEvent_t ev_sorted = nullptr, ev_halo_a = nullptr, ev_k4_late = nullptr, ev_halo_b = nullptr, ev_filled = nullptr;
-    bool overlap = true;              // WS_SLAB_OVERLAP=0 turns it off
+    bool overlap = true;              // WS_FLAG_NO_OVERLAP turns it off
     bool last_split = false;          // the last step ran K4 / K5 as early + late launches (refresh_accel repeats that)
     // WS_FLAG_GRAPH: captured steps, one per (quantised) launch bound
     std::vector<struct WsGraphEntry> graphs;

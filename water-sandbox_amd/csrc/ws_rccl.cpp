@@ -90,7 +90,7 @@ bool load_rccl()
 // couple the streams again (the next step's migration queuing behind halo B).  So the transport owns two
 // communicators -- the second one split off the first (ncclCommSplit: no second unique-id exchange) -- and every
 // stream keeps to its own: the first stream it sees gets comm[0], any other stream comm[1].
-// WS_RCCL_SINGLE_COMM=1 (or an RCCL without ncclCommSplit) keeps everything on comm[0], the pre-round-3 behaviour.
+// An RCCL without ncclCommSplit (or, in developer builds, WS_RCCL_SINGLE_COMM=1) keeps everything on comm[0], the pre-round-3 behaviour.
 struct RcclTransport {
     NcclComm comm[2] = {nullptr, nullptr};
     hipStream_t first_stream = nullptr;

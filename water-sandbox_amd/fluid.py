@@ -351,7 +351,8 @@ class FluidWorker:
     def stats(self):
         out = np.zeros(16, np.uint32)
         self._check(self._L.ws_read_stats(self._h, out.ctypes.data))
-        st = {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4])}
+        st = {"mask_overflow": int(out[0]), "cells_merged": tuple(int(x) for x in out[1:4]), "graph_steps": int(out[4]),
+              "tile_schedule": bool(out[15])}
         if out[6]:  # a slab handle: peaks of the fixed-capacity messages against their capacities
             st.update(halo_peak=int(out[5]), halo_capacity=int(out[6]), migration_peak=int(out[7]), migration_capacity=int(out[8]), far_peak=int(out[9]), far_capacity=int(out[10]),
                       migration_now=int(out[11]), halo_now=int(out[12]), far_now=int(out[13]))
