@@ -37,6 +37,23 @@
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// Workgroup -> tile map of the reorder pass and the two neighbour kernels.  Blocks are dealt round-robin over the 8 XCDs
+// (b and b + 8 share one), each with its own L2: tile = f(b) gives every XCD one CONTIGUOUS eighth of the sorted order (an
+// x-slab of the domain), so a tile's neighbour records are fetched into one L2 instead of into all eight (round 2) --
+// and the SAME eighth in k_reorder, K4 and K5 (round 5), walked in alternating directions: k_reorder ascending, K4
+// DESCENDING (`reverse`), K5 ascending.  So every kernel starts on what the kernel before it wrote LAST on this very
+// XCD -- the end of the range k_reorder has just filled is still in this XCD's L2 when K4 begins there, the accept masks
+// and densities K4 wrote last are where K5 begins (C3: K4 -9 % sparse, K5 -4 % settled; steps -3.2 % / -2.5 %; C2, the
+// reference's 65 536: -2.5 %; C4 settled -1.5 %; profiles/r05/ab/ab_zigzag_*.log).  Speed / traffic only: any
+// placement and any order compute the same thing.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nt, bool reverse = false)
+{
+    const uint32_t xcd = b & 7u, q = nt >> 3, r = nt & 7u;
+    const uint32_t first = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q, mine = q + (xcd < r ? 1u : 0u);
+    const uint32_t j = b >> 3;
+    return first + (reverse ? mine - 1u - j : j);
+}
+
 // ---------------------------------------------------------------------------------
 // cell helpers
 // ---------------------------------------------------------------------------------
@@ -488,8 +505,10 @@ __global__ void __launch_bounds__(WS_REORDER_BLOCK) k_reorder(WsDev d, const uin
                                                       uint32_t *__restrict__ cid_srt, WsXYZ sxyz)
 {
     __shared__ uint32_t s_id[WS_REORDER_BLOCK];  // the ids of this workgroup's slots (0xFFFFFFFF: nothing there)
-    const uint32_t k = blockIdx.x * WS_REORDER_BLOCK + threadIdx.x;
-    const uint32_t s = d.base + k, s0 = d.base + blockIdx.x * WS_REORDER_BLOCK;
+    // (single-GPU handles: every XCD fills the contiguous eighth of the sorted order it will work on in K4 / K5 -- xcd_tile)
+    const uint32_t blk = d.dyn ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
+    const uint32_t k = blk * WS_REORDER_BLOCK + threadIdx.x;
+    const uint32_t s = d.base + k, s0 = d.base + blk * WS_REORDER_BLOCK;
     bool active = k < ws_n(d);
     uint32_t i = 0, c = WS_DEAD;
     float4 p = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu)), v = p;
@@ -994,15 +1013,6 @@ __global__ void __launch_bounds__(WS_BLOCK) k_force_simple(WsDev d, const uint32
 #define ND_MASK_WORDS 64   // 2048 candidates per particle (256 B of mask rows each; only the words in use are touched)
 #endif
 
-// Workgroup -> tile map of the two neighbour kernels.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
-// share one), each with its own L2: tile = f(b) gives every XCD one CONTIGUOUS eighth of the sorted order (an
-// x-slab of the domain), so a tile's neighbour records are fetched into one L2 instead of into all eight.
-// Speed / traffic only: any placement computes the same thing.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nt)
-{
-    const uint32_t xcd = b & 7u, q = nt >> 3, r = nt & 7u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (b >> 3);
-}
 
 typedef float nd_f4 __attribute__((ext_vector_type(4)));
 typedef float nd_f4u __attribute__((ext_vector_type(4), aligned(4)));  // 4 consecutive floats, 4-byte aligned
@@ -1159,7 +1169,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
         const WsSpan sp = ws_span(d, start);
         const uint32_t ntiles = (sp.len + ND_P - 1u) / ND_P;  // <= gridDim.x: a slab launches over an upper bound
         if (blockIdx.x >= ntiles) return;
-        const uint32_t v = xcd_tile(blockIdx.x, ntiles) * ND_P + threadIdx.x;
+        const uint32_t v = xcd_tile(blockIdx.x, ntiles, true) * ND_P + threadIdx.x;  // (descending: see xcd_tile)
         const bool valid = v < sp.len;
         nd_tile<IEEE, CUT>(d, start, cid_srt, srt, sxyz, mask, stats, list, span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x);  // lanes past the end shadow the last particle
     }
