@@ -93,6 +93,11 @@ profiles_c)  # part 3: the other bench lines
   WS_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 20 --warmup 5 --reps 1 > $out/bench_gloo_rehearsal_2ranks.json 2> $out/bench_gloo_rehearsal_2ranks.err || echo "gloo rehearsal failed"
   python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
   ;;
+fuzz)  # fuzz <cases> <seed> <exact|lagged> [benign] : loopback slabs on this GPU against the single handle, bit for bit
+  mkdir -p $out/slab
+  timeout -k 10 1000 python3 tools/slab_fuzz.py ${1:-60} ${2:-20261006} ${3:-exact} $4 > $out/slab/slab_fuzz_${3:-exact}_seed${2:-20261006}.log 2>&1
+  echo "fuzz exit $?"; tail -2 $out/slab/slab_fuzz_${3:-exact}_seed${2:-20261006}.log
+  ;;
 mask_words)  # the accept-mask size at C5 settled (tools/ab/libbase.so, libmw128.so, libmw256.so)
   ABLATE_CONFIG=${1:-c5} python3 tools/ablate.py 400 base mw128 mw256 2>&1 | tee $out/mask_words_${1:-c5}.log
   ;;
