@@ -3,7 +3,7 @@
 clock over `steps` steps (best of three, no profiling) and the per-kernel means of a profiled run; the final states must be
 bit-identical.  (tools/ablate.py times ONE step right after the state upload -- right for K4 / K5, wrong for the sort
 phase, whose first step after an upload sorts from id order.)
-usage: lib_ab.py <config> <state step> <steps> <name> [<name> ...]"""
+usage: lib_ab.py <config | powK> <state step> <steps> <name> [<name> ...]"""
 import json
 import os
 import sys
@@ -16,7 +16,12 @@ sys.path.insert(0, ROOT)
 import water_sandbox_amd as ws  # noqa: E402
 
 cfg, warm, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-pos, params = ws.workloads.make_workload(cfg, "cloud")
+if cfg.startswith("pow"):  # pow20: 2^20 particles in the container the named configurations' rule gives that count
+    block = ws.workloads.block_for(1 << int(cfg[3:]))
+    params = ws.make_params(container_size=ws.workloads.container_for_block(block))
+    pos = ws.workloads.uniform_cloud(block[0] * block[1] * block[2], 0x5EED0100 + int(cfg[3:]), list(params.ext_min), list(params.ext_max))
+else:
+    pos, params = ws.workloads.make_workload(cfg, "cloud")
 w = ws.FluidWorker(pos, params)
 w.run(warm)
 state = w.read_vec("particles")

@@ -1175,9 +1175,22 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     }
 }
 
+// Mask words per particle up to which a wave takes the word-synchronous walk (nf_tile).  The walk gathers coherently
+// (every lane inside the same 32 candidates) but keeps ONE neighbour in flight and pays, per word, the busiest lane's
+// bit count; the per-lane iterator keeps two in flight and pays the busiest lane's total.  A launch of many rounds of
+// workgroups is bound by what its gathers cost the chip and gains from the walk in denser waves (10 against 8 words:
+// K5 -1.8 % settled at C3, -1.3 % at C4); a launch of a round or two is as long as its slowest tile, and there the
+// walk of a dense wave IS the slowest tile (10 words at 2^18 / 2^19 particles: K5 +24 % / +26 %; 6 against 8: -5 %).
+// 2^20 and 2^21 particles: +-1 % either way.  profiles/r05/ab/wordsync_by_launch_size.log
 #ifndef NF_WORDSYNC_MAX
-#define NF_WORDSYNC_MAX 8  // mask words per particle up to which a wave takes the word-synchronous walk.  Settled K5 at
-#endif                     // 8 / 10 words: C3 0.911 / 0.891 ms, but C2 0.068 / 0.085 ms -- 8 is the safe side
+#define NF_WORDSYNC_MAX 6
+#endif
+#ifndef NF_WORDSYNC_MAX_BIG
+#define NF_WORDSYNC_MAX_BIG 10       // ... in launches of at least
+#endif
+#ifndef NF_WORDSYNC_BIG_TILES
+#define NF_WORDSYNC_BIG_TILES 16384  // tiles (2^21 particles: four and a half rounds of resident workgroups)
+#endif
 #ifndef NF_P
 #define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
 #endif
@@ -1188,7 +1201,7 @@ template <bool IEEE, bool ACCEL_ONLY, bool CUT>
 __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restrict__ start, const uint32_t *__restrict__ cid_srt,
                                         WsSorted srt, WsSoA out, float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                         uint32_t *__restrict__ count, WsMask mask, uint32_t *t_end, uint32_t *t_delta,
-                                        const uint32_t iv, const bool valid, const uint32_t tid)
+                                        const uint32_t iv, const bool valid, const uint32_t tid, const uint32_t wordsync_max)
 {
     const uint32_t i = iv;
     const float4 o = srt.pred(iv);   // w = own density
@@ -1232,7 +1245,7 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
         const uint32_t nwords = (total + 31u) >> 5;
         uint32_t run = 0, end_r = t_end[tid], delta_r = t_delta[tid];
         const uint32_t self_s = i - t_delta[4 * NF_P + tid];  // own candidate number (own cell = run 4)
-      if (!any_over && !__ballot(nwords > (uint32_t)NF_WORDSYNC_MAX)) {
+      if (!any_over && !__ballot(nwords > wordsync_max)) {
         // A wave whose particles all have few candidates (the sparse state: 1-2 mask words each) walks its 64 masks
         // WORD BY WORD, all lanes on the same word number: inside a word every lane takes its set bits one per
         // trip (the neighbours in visit order).  The rare work -- next word, dropping the particle's own bit
@@ -1349,7 +1362,7 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         const uint32_t v = tile * NF_P + threadIdx.x;
         const bool valid = v < d.n;
         nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
-                                       d.base + (valid ? v : d.n - 1u), valid, threadIdx.x);
+                                       d.base + (valid ? v : d.n - 1u), valid, threadIdx.x, (uint32_t)NF_WORDSYNC_MAX);  // (scheduled launches are small ones)
         __syncthreads();  // (both waves of the tile are done)
         if (threadIdx.x == 0) sched.cost[tile] = (uint32_t)min(wall_clock64() - t0, 0xFFFFFFull) + 1u;
     } else {
@@ -1359,7 +1372,8 @@ __global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *
         const uint32_t v = xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
         const bool valid = v < sp.len;
         nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
-                                       span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x);  // lanes past the end shadow the last particle
+                                       span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x,  // lanes past the end shadow the last particle
+                                       ntiles >= (uint32_t)NF_WORDSYNC_BIG_TILES ? (uint32_t)NF_WORDSYNC_MAX_BIG : (uint32_t)NF_WORDSYNC_MAX);
     }
 }
 
