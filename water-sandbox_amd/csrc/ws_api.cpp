@@ -455,7 +455,7 @@ ws_status alloc_schedule(ws_handle *h)
     if (const char *v = WS_DEV_ENV("WS_SCHED_CLASSES")) h->sched_classes = (uint32_t)atoi(v);
     if (const char *v = WS_DEV_ENV("WS_SCHED_GROUP")) h->sched_group = (uint32_t)atoi(v);
     h->sched_tiles4 = (h->n + wsk_density_tile() - 1u) / wsk_density_tile();
-    h->sched_tiles5 = (h->n + wsk_force_tile() - 1u) / wsk_force_tile();
+    h->sched_tiles5 = (h->n + wsk_force_tile(h->n) - 1u) / wsk_force_tile(h->n);
     uint32_t *cost4 = nullptr;
     HIP_TRY(h, hipMalloc(&cost4, (size_t)h->sched_tiles4 * 4));
     HIP_TRY(h, hipMemsetAsync(cost4, 0, (size_t)h->sched_tiles4 * 4, h->stream));
@@ -472,7 +472,8 @@ ws_status alloc_schedule(ws_handle *h)
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sched_in, hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&h->ev_sched_out, hipEventDisableTiming));
     for (int k = 0; k < 2; k++)  // (costs all unknown: both sets come out as the equal shares)
-        wsk_schedule(h->stream, h->sched4[k], h->sched_tiles4, h->sched5[k], h->sched5[k], h->sched_tiles5, h->sched_classes, h->sched_group);
+        wsk_schedule(h->stream, h->sched4[k], h->sched_tiles4, h->sched5[k], h->sched5[k], h->sched_tiles5, h->sched_classes, h->sched_group,
+                     wsk_force_tile(h->n));
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->sched_parity = 0;
@@ -514,7 +515,7 @@ void enqueue_step(ws_handle *h)
         hipEventRecord(h->ev_sched_in, s);
         hipStreamWaitEvent(h->sched_stream, h->ev_sched_in, 0);
         wsk_schedule(h->sched_stream, h->sched4[par ^ 1u], h->sched_tiles4, h->sched5[par ^ 1u], h->sched5[par ^ 1u], h->sched_tiles5,
-                     h->sched_classes, h->sched_group);
+                     h->sched_classes, h->sched_group, wsk_force_tile(h->n));
         hipEventRecord(h->ev_sched_out, h->sched_stream);
         h->sched_parity = par ^ 1u;
     }

@@ -369,11 +369,11 @@ void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uin
                  const uint8_t *mult, bool alias, int variant, bool ieee, uint32_t *stats, WsMask mask, WsXYZ sxyz,
                  const WsEventPair *ev = nullptr, WsSched sched = WsSched{});
 uint32_t wsk_density_tile(void);  // particles per tile of the listed K4 / K5
-uint32_t wsk_force_tile(void);
+uint32_t wsk_force_tile(uint32_t n);  // particles per K5 workgroup in a launch over n particles
 uint32_t wsk_sched_grid(uint32_t ntiles);  // workgroups of a scheduled launch over ntiles tiles
 // s5_costs: the set whose cost array holds the K5 costs to schedule from (the set being written is read by nobody)
 void wsk_schedule(hipStream_t s, WsSched s4, uint32_t ntiles4, WsSched s5, WsSched s5_costs, uint32_t ntiles5, uint32_t nclasses,
-                  uint32_t group_particles);
+                  uint32_t group_particles, uint32_t tile5);
 uint32_t wsk_mask_words(void);
 void wsk_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
                float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias, int variant, bool ieee,

@@ -1191,13 +1191,23 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #ifndef NF_WORDSYNC_BIG_TILES
 #define NF_WORDSYNC_BIG_TILES 16384  // tiles (2^21 particles: four and a half rounds of resident workgroups)
 #endif
+// Particles per K5 workgroup (template parameter P of nf_tile / k_force_listed).  C3, 64 / 128 / 256 at step 60:
+// 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27 -- 128.  A launch of a round or two of workgroups is as long as
+// its slowest tile, and one-wave tiles are shorter and deal finer: 64 below NF_SMALL_BELOW particles (K5 -11 % at the
+// reference's 65 536, -5 % at 2^18 settled; +-0 at 2^19, +1.3 % at C3: profiles/r05/ab/k5_tile_by_launch_size.log)
 #ifndef NF_P
-#define NF_P 128  // particles per K5 workgroup (64 / 128 / 256 at step 60: 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27)
+#define NF_P 128
+#endif
+#ifndef NF_P_SMALL
+#define NF_P_SMALL 64
+#endif
+#ifndef NF_SMALL_BELOW
+#define NF_SMALL_BELOW (1u << 19)
 #endif
 
 // One tile of K5 (see nd_tile).  t_end / t_delta: the workgroup's LDS, a per-lane run table: candidate numbers
 // [t_end[r-1], t_end[r]) belong to run r, neighbour = number + t_delta[r]
-template <bool IEEE, bool ACCEL_ONLY, bool CUT>
+template <bool IEEE, bool ACCEL_ONLY, bool CUT, int P>
 __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restrict__ start, const uint32_t *__restrict__ cid_srt,
                                         WsSorted srt, WsSoA out, float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                         uint32_t *__restrict__ count, WsMask mask, uint32_t *t_end, uint32_t *t_delta,
@@ -1227,12 +1237,12 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const int r = 3 * p + q;
-                t_delta[r * NF_P + tid] = b[q] - total;
+                t_delta[r * P + tid] = b[q] - total;
                 total += e[q] - b[q];
-                t_end[r * NF_P + tid] = total;
+                t_end[r * P + tid] = total;
             }
         }
-        t_end[9 * NF_P + tid] = 0xFFFFFFFFu;
+        t_end[9 * P + tid] = 0xFFFFFFFFu;
         if (!valid) total = 0;
     }
     // A particle with more candidates than the accept mask holds (> 2 048: a cell column of the settled floor layer in the
@@ -1244,7 +1254,7 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
         const uint32_t *mrow = mask.words + (iv - d.base);
         const uint32_t nwords = (total + 31u) >> 5;
         uint32_t run = 0, end_r = t_end[tid], delta_r = t_delta[tid];
-        const uint32_t self_s = i - t_delta[4 * NF_P + tid];  // own candidate number (own cell = run 4)
+        const uint32_t self_s = i - t_delta[4 * P + tid];  // own candidate number (own cell = run 4)
       if (!any_over && !__ballot(nwords > wordsync_max)) {
         // A wave whose particles all have few candidates (the sparse state: 1-2 mask words each) walks its 64 masks
         // WORD BY WORD, all lanes on the same word number: inside a word every lane takes its set bits one per
@@ -1269,8 +1279,8 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
                     bits &= bits - 1u;
                     while (sc >= end_r) {
                         run++;
-                        end_r = t_end[run * NF_P + tid];
-                        delta_r = t_delta[min(run, 8u) * NF_P + tid];
+                        end_r = t_end[run * P + tid];
+                        delta_r = t_delta[min(run, 8u) * P + tid];
                     }
                     const uint32_t j = sc + delta_r;
                     q_n = srt.pred_near(j);
@@ -1313,8 +1323,8 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
             rest &= rest - 1u;
             while (sc >= end_r) {
                 run++;
-                end_r = t_end[run * NF_P + tid];
-                delta_r = t_delta[min(run, 8u) * NF_P + tid];
+                end_r = t_end[run * P + tid];
+                delta_r = t_delta[min(run, 8u) * P + tid];
             }
             j = sc + delta_r;
             return true;
@@ -1345,33 +1355,33 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
 }
 
 // (SCHED: see k_density_listed)
-template <bool IEEE, bool ACCEL_ONLY, bool CUT, bool SCHED>
-__global__ void __launch_bounds__(NF_P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
+template <bool IEEE, bool ACCEL_ONLY, bool CUT, bool SCHED, int P>
+__global__ void __launch_bounds__(P) k_force_listed(WsDev d, const uint32_t *__restrict__ start,
                                                        const uint32_t *__restrict__ cid_srt, WsSorted srt, WsSoA out,
                                                        float4 *__restrict__ accel, uint32_t *__restrict__ cid_out,
                                                        uint32_t *__restrict__ count, WsMask mask, WsSched sched)
 {
-    __shared__ uint32_t t_end[10 * NF_P];  // row 9: a sentinel no candidate number reaches
-    __shared__ uint32_t t_delta[9 * NF_P];
+    __shared__ uint32_t t_end[10 * P];  // row 9: a sentinel no candidate number reaches
+    __shared__ uint32_t t_delta[9 * P];
     if constexpr (SCHED) {
         const unsigned long long t0 = wall_clock64();
         const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
         const uint32_t s0 = sched.split[x], s1 = sched.split[x + 1];
         if (j >= s1 - s0) return;
         const uint32_t tile = sched.perm[s0 + j];
-        const uint32_t v = tile * NF_P + threadIdx.x;
+        const uint32_t v = tile * P + threadIdx.x;
         const bool valid = v < d.n;
-        nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
+        nf_tile<IEEE, ACCEL_ONLY, CUT, P>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
                                        d.base + (valid ? v : d.n - 1u), valid, threadIdx.x, (uint32_t)NF_WORDSYNC_MAX);  // (scheduled launches are small ones)
         __syncthreads();  // (both waves of the tile are done)
         if (threadIdx.x == 0) sched.cost[tile] = (uint32_t)min(wall_clock64() - t0, 0xFFFFFFull) + 1u;
     } else {
         const WsSpan sp = ws_span(d, start);
-        const uint32_t ntiles = (sp.len + NF_P - 1u) / NF_P;  // <= gridDim.x: a slab launches over an upper bound
+        const uint32_t ntiles = (sp.len + P - 1u) / P;  // <= gridDim.x: a slab launches over an upper bound
         if (blockIdx.x >= ntiles) return;
-        const uint32_t v = xcd_tile(blockIdx.x, ntiles) * NF_P + threadIdx.x;
+        const uint32_t v = xcd_tile(blockIdx.x, ntiles) * P + threadIdx.x;
         const bool valid = v < sp.len;
-        nf_tile<IEEE, ACCEL_ONLY, CUT>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
+        nf_tile<IEEE, ACCEL_ONLY, CUT, P>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
                                        span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x,  // lanes past the end shadow the last particle
                                        ntiles >= (uint32_t)NF_WORDSYNC_BIG_TILES ? (uint32_t)NF_WORDSYNC_MAX_BIG : (uint32_t)NF_WORDSYNC_MAX);
     }
@@ -1391,7 +1401,7 @@ uint32_t wsk_mask_words(void) { return ND_MASK_WORDS; }
 // workgroups of a scheduled launch: eight XCDs x the longest part of `perm` k_schedule ever gives one of them
 uint32_t wsk_sched_grid(uint32_t ntiles) { return 8u * (ntiles / 8u + ntiles / 16u + 2u); }
 uint32_t wsk_density_tile(void) { return ND_P; }
-uint32_t wsk_force_tile(void) { return NF_P; }
+uint32_t wsk_force_tile(uint32_t n) { return n < (uint32_t)NF_SMALL_BELOW ? (uint32_t)NF_P_SMALL : (uint32_t)NF_P; }
 
 template <bool IEEE>
 static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
@@ -1410,6 +1420,22 @@ static void launch_density(hipStream_t s, const WsDev &d, const uint32_t *start,
         WS_LAUNCH((k_density_listed<IEEE, false, false>), dim3(cdiv(d.n, ND_P)), dim3(ND_P), s, ev, d, start, cid_srt, srt, sxyz, mask, stats, sched);
 }
 
+// (d.n: the particle count of a single-GPU handle, a host-side upper bound of the range on a slab)
+template <bool IEEE, bool ACCEL_ONLY, int P>
+static void launch_force_listed(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt, WsSoA out,
+                                float4 *accel, uint32_t *cid_out, uint32_t *count, WsMask mask, const WsEventPair *ev, WsSched sched)
+{
+    if (d.dyn && d.range_sel == WS_RANGE_EARLY)
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, true, false, P>), dim3(cdiv(d.n, P)), dim3(P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask, sched);
+    else if (sched.perm && !d.dyn)
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, true, P>), dim3(wsk_sched_grid(cdiv(d.n, P))), dim3(P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask, sched);
+    else
+        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, false, P>), dim3(cdiv(d.n, P)), dim3(P), s, ev, d, start, cid_srt, srt, out,
+                  accel, cid_out, count, mask, sched);
+}
+
 template <bool IEEE, bool ACCEL_ONLY>
 static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
                          WsSoA out, float4 *accel, uint32_t *cid_out, uint32_t *count, const uint8_t *mult, bool alias,
@@ -1421,15 +1447,10 @@ static void launch_force(hipStream_t s, const WsDev &d, const uint32_t *start, c
     else if (variant == WS_VARIANT_SIMPLE)
         WS_LAUNCH((k_force_simple<false, IEEE, ACCEL_ONLY>), dim3(cdiv(d.n, WS_BLOCK)), dim3(WS_BLOCK), s, ev, d, start, cid_srt,
                   srt, out, accel, cid_out, count, mult);
-    else if (d.dyn && d.range_sel == WS_RANGE_EARLY)
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, true, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
-                  accel, cid_out, count, mask, sched);
-    else if (sched.perm && !d.dyn)
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, true>), dim3(wsk_sched_grid(cdiv(d.n, NF_P))), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
-                  accel, cid_out, count, mask, sched);
+    else if (wsk_force_tile(d.n) == (uint32_t)NF_P_SMALL)
+        launch_force_listed<IEEE, ACCEL_ONLY, NF_P_SMALL>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mask, ev, sched);
     else
-        WS_LAUNCH((k_force_listed<IEEE, ACCEL_ONLY, false, false>), dim3(cdiv(d.n, NF_P)), dim3(NF_P), s, ev, d, start, cid_srt, srt, out,
-                  accel, cid_out, count, mask, sched);
+        launch_force_listed<IEEE, ACCEL_ONLY, NF_P>(s, d, start, cid_srt, srt, out, accel, cid_out, count, mask, ev, sched);
 }
 
 void wsk_density(hipStream_t s, const WsDev &d, const uint32_t *start, const uint32_t *cid_srt, WsSorted srt,
@@ -1486,7 +1507,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
 }
 
 __global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_t nt4, WsSched s5, uint32_t nt5, uint32_t nclasses,
-                                                             uint32_t group_particles)
+                                                             uint32_t group_particles, uint32_t tile5)
 {
     __shared__ uint32_t s_w[WS_SCHED_BLOCK / 64];
     __shared__ uint32_t s_cut[9];
@@ -1497,7 +1518,7 @@ __global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_
     if (T == 0u) return;
     // tiles are classed in GROUPS of neighbours in the sorted order (a group = about one row of cells): a class is a set
     // of whole groups, so the tiles that run side by side still come from one neighbourhood
-    const uint32_t G = max(group_particles / (second ? (uint32_t)NF_P : (uint32_t)ND_P), 1u);
+    const uint32_t G = max(group_particles / (second ? tile5 : (uint32_t)ND_P), 1u);
     // ---- the cuts: tile ranges of equal summed cost
     const uint32_t per = (T + WS_SCHED_BLOCK - 1u) / WS_SCHED_BLOCK;
     const uint32_t a = min(tid * per, T), b = min(a + per, T);
@@ -1624,11 +1645,11 @@ __global__ void __launch_bounds__(WS_SCHED_BLOCK) k_schedule(WsSched s4, uint32_
 }
 
 void wsk_schedule(hipStream_t s, WsSched s4, uint32_t ntiles4, WsSched s5, WsSched s5_costs, uint32_t ntiles5, uint32_t nclasses,
-                  uint32_t group_particles)
+                  uint32_t group_particles, uint32_t tile5)
 {
     nclasses = std::min<uint32_t>(std::max<uint32_t>(nclasses, 1u), WS_SCHED_CLASSES);
     s5.cost = s5_costs.cost;  // (the kernel reads costs and writes split / perm)
-    hipLaunchKernelGGL(k_schedule, dim3(16), dim3(WS_SCHED_BLOCK), 0, s, s4, ntiles4, s5, ntiles5, nclasses, group_particles);
+    hipLaunchKernelGGL(k_schedule, dim3(16), dim3(WS_SCHED_BLOCK), 0, s, s4, ntiles4, s5, ntiles5, nclasses, group_particles, tile5);
 }
 
 // ---------------------------------------------------------------------------------
