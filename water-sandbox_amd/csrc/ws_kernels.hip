@@ -1191,6 +1191,9 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #ifndef NF_WORDSYNC_BIG_TILES
 #define NF_WORDSYNC_BIG_TILES 16384  // tiles (2^21 particles: four and a half rounds of resident workgroups)
 #endif
+#ifndef NF_WORDSYNC_MAX_IEEE
+#define NF_WORDSYNC_MAX_IEEE 8       // WS_FLAG_IEEE_DIVISION: a pair costs ~2.7 x the instructions, so does every lockstep trip of the walk (10 words: K5 1.45 -> 1.73 ms settled at C3)
+#endif
 // Particles per K5 workgroup (template parameter P of nf_tile / k_force_listed).  C3, 64 / 128 / 256 at step 60:
 // 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27 -- 128.  A launch of a round or two of workgroups is as long as
 // its slowest tile, and one-wave tiles are shorter and deal finer: 64 below NF_SMALL_BELOW particles (K5 -11 % at the
@@ -1372,7 +1375,7 @@ __global__ void __launch_bounds__(P) k_force_listed(WsDev d, const uint32_t *__r
         const uint32_t v = tile * P + threadIdx.x;
         const bool valid = v < d.n;
         nf_tile<IEEE, ACCEL_ONLY, CUT, P>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
-                                       d.base + (valid ? v : d.n - 1u), valid, threadIdx.x, (uint32_t)NF_WORDSYNC_MAX);  // (scheduled launches are small ones)
+                                       d.base + (valid ? v : d.n - 1u), valid, threadIdx.x, (uint32_t)(IEEE ? NF_WORDSYNC_MAX_IEEE : NF_WORDSYNC_MAX));  // (scheduled launches are small ones)
         __syncthreads();  // (both waves of the tile are done)
         if (threadIdx.x == 0) sched.cost[tile] = (uint32_t)min(wall_clock64() - t0, 0xFFFFFFull) + 1u;
     } else {
@@ -1383,7 +1386,7 @@ __global__ void __launch_bounds__(P) k_force_listed(WsDev d, const uint32_t *__r
         const bool valid = v < sp.len;
         nf_tile<IEEE, ACCEL_ONLY, CUT, P>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
                                        span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x,  // lanes past the end shadow the last particle
-                                       ntiles >= (uint32_t)NF_WORDSYNC_BIG_TILES ? (uint32_t)NF_WORDSYNC_MAX_BIG : (uint32_t)NF_WORDSYNC_MAX);
+                                       IEEE ? (uint32_t)NF_WORDSYNC_MAX_IEEE : ntiles >= (uint32_t)NF_WORDSYNC_BIG_TILES ? (uint32_t)NF_WORDSYNC_MAX_BIG : (uint32_t)NF_WORDSYNC_MAX);
     }
 }
 
