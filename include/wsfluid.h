@@ -421,7 +421,7 @@ ws_status ws_profile_select(ws_handle *h, uint32_t kernel_mask);
  * the NEXT step's will (sized from what every rank reported a few steps ago; the capacities with
  * WS_FLAG_FIXED_MESSAGES); 0 without peers; out[14] = how often ws_step has waited for message sizes so far (two per
  * step with exact sizes, never with WS_FLAG_LAGGED_MESSAGES); out[15] = 1 when the cost-guided tile schedule drives the
- * neighbour kernels (single-GPU handles of 2^17 .. 2^20 particles, not in a captured step: DESIGN.md 3). */
+ * neighbour kernels (single-GPU handles of 2^18 <= n < 2^20 particles, not in a captured step: DESIGN.md 3). */
 ws_status ws_read_stats(ws_handle *h, uint32_t out[16]);
 /* Device cell grid actually in use (cells along x,y,z incl. padding).  The reference's N-bucket hashed table has the
  * same size for every smoothing radius (assets/simulation.wgsl:125-128); a dense grid does not, so when

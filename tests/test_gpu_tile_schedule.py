@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_which_handles_take_the_schedule(ws):
-    """2^17 .. 2^20 particles (C2), not the reference's 65 536, not C1, not a captured step."""
+    """2^18 <= n < 2^20 particles (C2), not the reference's 65 536, not C1, not a captured step."""
     taken = {}
     for cfg, graph in (("c1", False), ("ref", False), ("c2", False), ("c2", True)):
         pos, params = ws.workloads.make_workload(cfg, "cloud")

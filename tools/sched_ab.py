@@ -17,7 +17,12 @@ import water_sandbox_amd as ws  # noqa: E402
 
 cfg, warm, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 L = ws.fluid.bind_library(ws.build.build_dev_library())
-pos, params = ws.workloads.make_workload(cfg, "cloud")
+if cfg.startswith("pow"):  # pow19: 2^19 particles in the container the named configurations' rule gives that count
+    block = ws.workloads.block_for(1 << int(cfg[3:]))
+    params = ws.make_params(container_size=ws.workloads.container_for_block(block))
+    pos = ws.workloads.uniform_cloud(block[0] * block[1] * block[2], 0x5EED0100 + int(cfg[3:]), list(params.ext_min), list(params.ext_max))
+else:
+    pos, params = ws.workloads.make_workload(cfg, "cloud")
 os.environ["WS_TILE_SCHEDULE"] = "0"
 w = ws.FluidWorker(pos, params, library=L)
 w.run(warm)

@@ -413,16 +413,18 @@ void bound_pending(ws_handle *h)
 
 // The tile schedule of a single-GPU handle's K4 / K5 (WsSched, ws_internal.h): split / perm / cost per kernel in two
 // sets, a stream and two events for k_schedule.  Built once here with no costs known: equal shares, tiles in their own
-// order.  Only handles of WS_SCHED_MIN_PARTICLES .. WS_SCHED_MAX_PARTICLES particles take it (profiles/r05/sched/):
-//   * there (C2: 262 144 particles) a neighbour kernel is ONE round of workgroups -- the whole grid is resident at once
-//     -- so it lasts as long as its slowest workgroup lives, and starting the expensive tiles first is worth 20 % of
-//     both kernels (step -12 % settled, -10 % sparse);
-//   * below (the reference's own 65 536 particles, C1) the kernels gain 4-6 % but the step is launch-bound and the extra
-//     launch with its two cross-stream events costs 8 us of a 75 us step;
-//   * above (C3, C4) an XCD works through many rounds, the equal static shares are within 4 % of balanced, and every
-//     reordering of the tiles costs more in L2 locality than the shorter drain returns (K5 +4 ... +13 %).
-#define WS_SCHED_MIN_PARTICLES (1u << 17)
-#define WS_SCHED_MAX_PARTICLES (1u << 20)
+// order.  Only handles of WS_SCHED_MIN_PARTICLES <= n < WS_SCHED_END_PARTICLES take it (profiles/r05/sched/; the
+// range re-measured on the round's final kernels: sched_range_final_kernels.log):
+//   * there (C2: 262 144 particles; 2^19) a neighbour kernel is one or two rounds of workgroups -- most of the grid is
+//     resident at once -- so it lasts as long as its slowest workgroup lives, and starting the expensive tiles first is
+//     worth 10-19 % of K4 and 5-15 % of K5 (step -7.6 % settled at C2, -7 % at 2^19, -5 % sparse);
+//   * below (the reference's own 65 536 particles: +12 %; 2^17: K4 -8 %, K5 -3 %, step +4 %) the step is launch-bound and
+//     the extra launch with its two cross-stream events costs 5-8 us of a 75-110 us step;
+//   * above (2^20 settled: K5 +8 %, step +3.8 %; 2^21: +6 %; C3, C4) an XCD works through many rounds, the equal static
+//     shares are within 4 % of balanced, and every reordering of the tiles costs more in L2 locality than the shorter
+//     drain returns (K5 +4 ... +13 %).  (2^20 in the sparse state would still gain 4 %: the settled state decides.)
+#define WS_SCHED_MIN_PARTICLES (1u << 18)
+#define WS_SCHED_END_PARTICLES (1u << 20)
 
 void free_schedule(ws_handle *h)
 {
@@ -446,7 +448,7 @@ void free_schedule(ws_handle *h)
 ws_status alloc_schedule(ws_handle *h)
 {
     if (h->variant != WS_VARIANT_LISTED || h->slab) return WS_OK;
-    uint32_t min_n = WS_SCHED_MIN_PARTICLES, max_n = WS_SCHED_MAX_PARTICLES;
+    uint32_t min_n = WS_SCHED_MIN_PARTICLES, max_n = WS_SCHED_END_PARTICLES - 1u;
     if (const char *v = WS_DEV_ENV("WS_TILE_SCHEDULE")) {  // developer builds: 0 = never, 1 = at every size (A/B runs)
         min_n = 0;
         max_n = atoi(v) ? 0xFFFFFFFFu : 0u;
