@@ -1175,18 +1175,19 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
     }
 }
 
-// Mask words per particle up to which a wave takes the word-synchronous walk (nf_tile).  The walk gathers coherently
-// (every lane inside the same 32 candidates) but keeps ONE neighbour in flight and pays, per word, the busiest lane's
+// Mask words per particle up to which a wave takes the in-step walk (nf_tile).  The walk gathers coherently (every
+// lane inside the same pair of mask words) but keeps ONE neighbour in flight and pays, per pair, the busiest lane's
 // bit count; the per-lane iterator keeps two in flight and pays the busiest lane's total.  A launch of many rounds of
-// workgroups is bound by what its gathers cost the chip and gains from the walk in denser waves (10 against 8 words:
-// K5 -1.8 % settled at C3, -1.3 % at C4); a launch of a round or two is as long as its slowest tile, and there the
-// walk of a dense wave IS the slowest tile (10 words at 2^18 / 2^19 particles: K5 +24 % / +26 %; 6 against 8: -5 %).
-// 2^20 and 2^21 particles: +-1 % either way.  profiles/r05/ab/wordsync_by_launch_size.log
+// workgroups is bound by what its gathers cost the chip and gains from the walk in denser waves (word by word, 10
+// against 8 words: K5 -1.8 % settled at C3, -1.3 % at C4; pair by pair, 12: -3.8 % more, 13: +-0, 14: +3 %); a launch
+// of a round or two is as long as its slowest tile, and there the walk of a dense wave IS the slowest tile (10 words
+// at 2^18 / 2^19 particles: K5 +24 % / +26 %; 6 against 8: -5 %).  2^20 and 2^21 particles: +-1 % either way.
+// profiles/r05/ab/wordsync_by_launch_size.log, k5_walk_word_pairs.log
 #ifndef NF_WORDSYNC_MAX
 #define NF_WORDSYNC_MAX 6
 #endif
 #ifndef NF_WORDSYNC_MAX_BIG
-#define NF_WORDSYNC_MAX_BIG 10       // ... in launches of at least
+#define NF_WORDSYNC_MAX_BIG 12       // ... in launches of at least
 #endif
 #ifndef NF_WORDSYNC_BIG_TILES
 #define NF_WORDSYNC_BIG_TILES 16384  // tiles (2^21 particles: four and a half rounds of resident workgroups)
@@ -1250,7 +1251,7 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
     }
     // A particle with more candidates than the accept mask holds (> 2 048: a cell column of the settled floor layer in the
     // tall containers) has no mask and takes the plain sweep -- that particle alone: the other lanes of its wave walk
-    // their masks (with the per-lane iterator: the word-synchronous walk needs the whole wave).
+    // their masks (with the per-lane iterator: the in-step walk needs the whole wave).
     const bool over = total > 32u * ND_MASK_WORDS;
     const bool any_over = __ballot(over) != 0ull;
     if (!over) {
@@ -1260,26 +1261,30 @@ __device__ __forceinline__ void nf_tile(const WsDev &d, const uint32_t *__restri
         const uint32_t self_s = i - t_delta[4 * P + tid];  // own candidate number (own cell = run 4)
       if (!any_over && !__ballot(nwords > wordsync_max)) {
         // A wave whose particles all have few candidates (the sparse state: 1-2 mask words each) walks its 64 masks
-        // WORD BY WORD, all lanes on the same word number: inside a word every lane takes its set bits one per
-        // trip (the neighbours in visit order).  The rare work -- next word, dropping the particle's own bit
-        // (simulation.wgsl:232 `particle_index == neighbour_index`) -- is done by all lanes at once, once per
-        // word; only the run switch stays per lane.  One neighbour's records are in flight while the previous
-        // one computes.  (C3, K5: -11 % at 21 candidates per particle, +24 % at 259 -- where a word's bit count
-        // differs too much between lanes -- hence the choice per wave.)
-        uint32_t wnext = nwords ? mrow[0] : 0u;  // one mask word ahead
+        // IN STEP, all lanes inside the same PAIR of mask words (64 candidates): inside a pair every lane takes its set
+        // bits one per trip (the neighbours in visit order), so the wave's gathers stay inside a few cells.  The rare
+        // work -- next pair, dropping the particle's own bit (simulation.wgsl:232 `particle_index == neighbour_index`)
+        // -- is done by all lanes at once, once per pair; only the run switch stays per lane.  One neighbour's records
+        // are in flight while the previous one computes.  The walk pays every pair's busiest lane (word by word, until
+        // round 5, every WORD's: 9 x ~10 trips for 44 neighbours; a pair's busiest lane is less far above the average:
+        // K5 -3.8 % settled at C3, -2.8 % at C4, -7 % at 65 536 particles; groups of four words lose the coherence
+        // again: profiles/r05/ab/k5_walk_word_pairs.log), which is why a wave of denser particles takes the per-lane
+        // iterator below (the limits: NF_WORDSYNC_MAX...).
+        uint32_t wn0 = nwords ? mrow[0] : 0u, wn1 = nwords > 1u ? mrow[mask.stride] : 0u;  // one pair ahead
         bool pend = false;
         float4 q_p = o, nvel_p = vel;
-        for (uint32_t w = 0; __ballot(w < nwords); w++) {
-            uint32_t bits = w < nwords ? wnext : 0u;
-            if (w == (self_s >> 5)) bits &= ~(1u << (self_s & 31u));
-            wnext = w + 1u < nwords ? mrow[(size_t)(w + 1u) * mask.stride] : 0u;
+        for (uint32_t w = 0; __ballot(w < nwords); w += 2u) {
+            unsigned long long bits = (w < nwords ? (unsigned long long)wn0 : 0ull) | (w + 1u < nwords ? (unsigned long long)wn1 << 32 : 0ull);
+            if ((w >> 1) == (self_s >> 6)) bits &= ~(1ull << (self_s & 63u));
+            wn0 = w + 2u < nwords ? mrow[(size_t)(w + 2u) * mask.stride] : 0u;
+            wn1 = w + 3u < nwords ? mrow[(size_t)(w + 3u) * mask.stride] : 0u;
             const uint32_t wbase = w << 5;
-            while (__ballot(bits != 0u)) {
-                const bool has = bits != 0u;
+            while (__ballot(bits != 0ull)) {
+                const bool has = bits != 0ull;
                 float4 q_n = q_p, nvel_n = nvel_p;
                 if (has) {
-                    const uint32_t sc = wbase + (uint32_t)__ffs((int)bits) - 1u;
-                    bits &= bits - 1u;
+                    const uint32_t sc = wbase + (uint32_t)__ffsll((long long)bits) - 1u;
+                    bits &= bits - 1ull;
                     while (sc >= end_r) {
                         run++;
                         end_r = t_end[run * P + tid];
