@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #define NF_WORDSYNC_BIG_TILES 16384  // tiles (2^21 particles: four and a half rounds of resident workgroups)
 #endif
 #ifndef NF_WORDSYNC_MAX_IEEE
-#define NF_WORDSYNC_MAX_IEEE 8       // WS_FLAG_IEEE_DIVISION: a pair costs ~2.7 x the instructions, so does every lockstep trip of the walk (10 words: K5 1.45 -> 1.73 ms settled at C3)
+#define NF_WORDSYNC_MAX_IEEE 4       // WS_FLAG_IEEE_DIVISION: a pair costs ~2.7 x the instructions, so does every lockstep trip of the walk (C3 settled K5, limit 2 / 4 / 6 / 8 / 10 / 12 words: 1.320 / 1.327 / 1.352 / 1.399 / 1.581 / 1.878 ms; tools/ieee_ab.sh)
 #endif
 // Particles per K5 workgroup (template parameter P of nf_tile / k_force_listed).  C3, 64 / 128 / 256 at step 60:
 // 0.43 / 0.43 / 0.54 ms, step 200: 1.57 / 1.35 / 1.27 -- 128.  A launch of a round or two of workgroups is as long as
