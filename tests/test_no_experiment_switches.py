@@ -23,7 +23,7 @@ def test_product_sources_have_no_experiment_switches():
             assert m not in text, "%s mentions %s" % (f, m)
     # the only conditional compilation left in the kernels: six tuning defaults and the test-only build's include
     conds = re.findall(r"^#\s*(?:if|ifdef|ifndef)\s+(\w+)", open(os.path.join(CSRC, "ws_kernels.hip")).read(), flags=re.M)
-    assert sorted(conds) == sorted(["ND_P", "ND_K", "ND_MASK_WORDS", "NF_WORDSYNC_MAX", "NF_WORDSYNC_MAX_BIG", "NF_WORDSYNC_BIG_TILES", "NF_WORDSYNC_MAX_IEEE", "NF_P", "NF_P_SMALL", "NF_SMALL_BELOW", "WS_REORDER_BLOCK", "WS_WITH_REFCHECK"]), conds
+    assert sorted(conds) == sorted(["ND_P", "ND_K", "ND_MASK_WORDS", "NF_WORDSYNC_MAX", "NF_WORDSYNC_MAX_BIG", "NF_WORDSYNC_BIG_TILES", "NF_WORDSYNC_MAX_IEEE", "NF_WORDSYNC_MAX_TINY", "NF_WORDSYNC_TINY_TILES", "NF_P", "NF_P_SMALL", "NF_SMALL_BELOW", "WS_REORDER_BLOCK", "WS_WITH_REFCHECK"]), conds
 
 
 # every environment hook the sources know (csrc/ws_devhooks.h: compiled in with -DWS_DEV_HOOKS only)

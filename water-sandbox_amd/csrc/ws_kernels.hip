@@ -1192,6 +1192,12 @@ __global__ void __launch_bounds__(ND_P) k_density_listed(WsDev d, const uint32_t
 #ifndef NF_WORDSYNC_BIG_TILES
 #define NF_WORDSYNC_BIG_TILES 16384  // tiles (2^21 particles: four and a half rounds of resident workgroups)
 #endif
+#ifndef NF_WORDSYNC_MAX_TINY
+#define NF_WORDSYNC_MAX_TINY 4       // ... and in launches of fewer than
+#endif
+#ifndef NF_WORDSYNC_TINY_TILES
+#define NF_WORDSYNC_TINY_TILES 2048  // tiles (the reference's 65 536 particles: every wave alone on its SIMD; 4 against 6 words: K5 -5 %, step -2 %; 2^17: +-0)
+#endif
 #ifndef NF_WORDSYNC_MAX_IEEE
 #define NF_WORDSYNC_MAX_IEEE 4       // WS_FLAG_IEEE_DIVISION: a pair costs ~2.7 x the instructions, so does every lockstep trip of the walk (C3 settled K5, limit 2 / 4 / 6 / 8 / 10 / 12 words: 1.320 / 1.327 / 1.352 / 1.399 / 1.581 / 1.878 ms; tools/ieee_ab.sh)
 #endif
@@ -1391,7 +1397,8 @@ __global__ void __launch_bounds__(P) k_force_listed(WsDev d, const uint32_t *__r
         const bool valid = v < sp.len;
         nf_tile<IEEE, ACCEL_ONLY, CUT, P>(d, start, cid_srt, srt, out, accel, cid_out, count, mask, t_end, t_delta,
                                        span_at(sp, valid ? v : sp.len - 1u), valid, threadIdx.x,  // lanes past the end shadow the last particle
-                                       IEEE ? (uint32_t)NF_WORDSYNC_MAX_IEEE : ntiles >= (uint32_t)NF_WORDSYNC_BIG_TILES ? (uint32_t)NF_WORDSYNC_MAX_BIG : (uint32_t)NF_WORDSYNC_MAX);
+                                       IEEE ? (uint32_t)NF_WORDSYNC_MAX_IEEE : ntiles >= (uint32_t)NF_WORDSYNC_BIG_TILES ? (uint32_t)NF_WORDSYNC_MAX_BIG
+                                                                     : ntiles >= (uint32_t)NF_WORDSYNC_TINY_TILES ? (uint32_t)NF_WORDSYNC_MAX : (uint32_t)NF_WORDSYNC_MAX_TINY);
     }
 }
 
